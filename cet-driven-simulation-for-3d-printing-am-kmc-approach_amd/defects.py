@@ -1,0 +1,46 @@
+"""Diagnostic point-defect mask on carbon sites (drop-in for the reference ``defects.py``).
+
+Host-side NumPy: the mask is drawn from NumPy's *global* legacy stream in row-major order
+of the C sites, exactly like the reference (defects.py:4-19), because ``run_kmc`` shares
+that stream with the orientation draws.
+"""
+import numpy as np
+
+from constants import DEFECT_PROB_BASE, K_T, T_SUB
+
+_C_SITE = 3        # STATES['C'], hard-coded in the reference (defects.py:8)
+_DEFECT_STATE = 4  # STATES['Defect'] (defects.py:29)
+
+
+def track_defects(state, atom_type, L, T=None):
+    """0/1 mask: each C site is flagged with p = 0.12*exp(-0.3/(kT*T)) (defects.py:4-19)."""
+    if L == 0:
+        return np.zeros((0, 0, 0), dtype=int)
+    mask = np.zeros((L, L, L), dtype=int)
+    sites = atom_type == _C_SITE
+    n_sites = int(np.count_nonzero(sites))
+    if n_sites:
+        if T is None:
+            p = np.full(n_sites, DEFECT_PROB_BASE)
+        else:
+            t_here = T[sites]
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t_here = np.where(t_here > 0, t_here, T_SUB)
+                p = DEFECT_PROB_BASE * np.exp(-0.3 / (K_T * t_here))
+        p = np.clip(p, 0.0, 1.0)
+        mask[sites] = (np.random.random(n_sites) < p).astype(int)
+    return mask
+
+
+def get_defect_density(defects, voxel_size=5e-6):
+    """Flagged sites per cubic metre (defects.py:21-23)."""
+    volume = defects.size * (voxel_size ** 3)
+    return np.sum(defects) / volume if volume > 0 else 0.0
+
+
+def introduce_defects(state, atom_type, T=None, apply_to_state=False, voxel_size=5e-6):
+    """(mask, density); optionally writes state 4 into flagged sites (defects.py:25-31)."""
+    mask = track_defects(state, atom_type, state.shape[0], T)
+    if apply_to_state:
+        state[mask == 1] = _DEFECT_STATE
+    return mask, get_defect_density(mask, voxel_size)
