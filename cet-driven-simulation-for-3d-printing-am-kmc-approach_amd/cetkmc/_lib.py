@@ -1,0 +1,121 @@
+"""Loader + ctypes prototypes for include/cetkmc.h."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
+INCLUDE = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include")
+SO_PATH = os.path.join(CSRC, "libcetkmc_hip.so")
+SOURCES = [os.path.join(CSRC, f) for f in ("cetkmc_hip.hip", "kernels.hpp", "voxel.hpp")] + [os.path.join(INCLUDE, "cetkmc.h")]
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+               "-fno-fast-math", "-I/opt/rocm/include"]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("nu", C.c_double), ("nu_dep", C.c_double), ("E_b", C.c_double * 3), ("E_diff", C.c_double * 3),
+        ("kT", C.c_double), ("T_melt", C.c_double), ("I0", C.c_double), ("delta_T_c", C.c_double),
+        ("K_nuc", C.c_double), ("beta_imp_nuc", C.c_double), ("max_imp_frac", C.c_double),
+        ("rate_threshold", C.c_double), ("anisotropy", C.c_double), ("impurity_re", C.c_double),
+        ("impurity_c", C.c_double),
+        ("alpha", C.c_double), ("inv_dx2", C.c_double), ("T_clip_lo", C.c_double), ("T_clip_hi", C.c_double),
+        ("T_nan", C.c_double), ("rho_cp", C.c_double), ("latent_coef", C.c_double),
+    ]
+
+
+class Event(C.Structure):
+    _fields_ = [("type", C.c_int32), ("pos", C.c_int32 * 3), ("target", C.c_int32 * 3), ("atom", C.c_int32),
+                ("rate", C.c_double), ("dep_rank", C.c_int64), ("theta", C.c_double), ("phi", C.c_double)]
+
+
+class SweepInfo(C.Structure):
+    _fields_ = [("total", C.c_double), ("n_events", C.c_int64), ("n_dep", C.c_int64)]
+
+
+class RunArgs(C.Structure):
+    _fields_ = [
+        ("step0", C.c_int64), ("n_steps", C.c_int64), ("defect_fraction", C.c_double),
+        ("u_pick", C.POINTER(C.c_double)), ("u_defect", C.POINTER(C.c_double)), ("u_np", C.POINTER(C.c_double)),
+        ("np_cap", C.c_int64), ("rng_mode", C.c_int32), ("seed", C.c_uint64), ("thermal_mode", C.c_int32),
+        ("thermal_dt", C.c_double), ("q_planes", C.POINTER(C.c_double)), ("n_q", C.c_int64),
+        ("use_latent", C.c_int32), ("profile", C.c_int32),
+    ]
+
+
+class RunResult(C.Structure):
+    _fields_ = [
+        ("steps_done", C.c_int64), ("status", C.c_int32), ("np_used", C.c_int64), ("q_used", C.c_int64),
+        ("nucleation_count", C.c_int64), ("sweep_ms_total", C.c_double), ("sweep_launches", C.c_int64),
+        ("wall_ms", C.c_double),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/cetkmc.h declares
+_P = C.POINTER
+PROTOTYPES = {
+    "cetkmc_last_error": (C.c_char_p, []),
+    "cetkmc_abi_version": (C.c_int, []),
+    "cetkmc_device_count": (C.c_int, [_P(C.c_int)]),
+    "cetkmc_create": (C.c_int, [_P(Params), C.c_int, C.c_int, _P(C.c_int), _P(C.c_void_p)]),
+    "cetkmc_get_unique_id": (C.c_int, [C.c_char_p]),
+    "cetkmc_create_rank": (C.c_int, [_P(Params), C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, _P(C.c_void_p)]),
+    "cetkmc_destroy": (C.c_int, [C.c_void_p]),
+    "cetkmc_set_params": (C.c_int, [C.c_void_p, _P(Params)]),
+    "cetkmc_sync": (C.c_int, [C.c_void_p]),
+    "cetkmc_owned_planes": (C.c_int, [C.c_void_p, _P(C.c_int), _P(C.c_int)]),
+    "cetkmc_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cetkmc_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cetkmc_upload_planes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cetkmc_download_planes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cetkmc_set_defects": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cetkmc_set_prev_state": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cetkmc_thermal_cet": (C.c_int, [C.c_void_p, C.c_double, C.c_int]),
+    "cetkmc_thermal_laser": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_int]),
+    "cetkmc_rate_sweep": (C.c_int, [C.c_void_p, _P(SweepInfo)]),
+    "cetkmc_select": (C.c_int, [C.c_void_p, C.c_double, _P(Event)]),
+    "cetkmc_apply": (C.c_int, [C.c_void_p, _P(Event), C.c_double, C.c_double, C.c_int]),
+    "cetkmc_enumerate_events": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _P(C.c_int64)]),
+    "cetkmc_row_sums": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cetkmc_run_steps": (C.c_int, [C.c_void_p, _P(RunArgs), _P(RunResult), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cetkmc_nucleation_count": (C.c_int64, [C.c_void_p]),
+    "cetkmc_reset_counters": (C.c_int, [C.c_void_p]),
+    "cetkmc_time_sweeps": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_double)]),
+}
+
+
+def build_library(force=False, verbose=False):
+    """hipcc cross-compiles for gfx950 without a GPU; the .so stays in-tree (csrc/)."""
+    newest = max(os.path.getmtime(s) for s in SOURCES)
+    if not force and os.path.exists(SO_PATH) and os.path.getmtime(SO_PATH) >= newest:
+        return SO_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, "cetkmc_hip.hip"), "-o", SO_PATH, "-ldl"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return SO_PATH
+
+
+_lib = None
+
+
+def load():
+    """Load libcetkmc_hip.so; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(
+            f"{SO_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  cetkmc has no CPU fallback.")
+    lib = C.CDLL(SO_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.cetkmc_abi_version() != 1:
+        raise RuntimeError("libcetkmc_hip.so ABI version mismatch")
+    _lib = lib
+    return lib

@@ -1,0 +1,883 @@
+// cetkmc_hip.hip -- C ABI (include/cetkmc.h) + host orchestration of the HIP kernels.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off
+//        -fno-fast-math cetkmc_hip.hip -o libcetkmc_hip.so -ldl
+// RCCL is dlopen()ed lazily (only multi-process runs need it).  There is no CPU fallback:
+// every compute entry point fails if no HIP device is usable.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+using namespace cetkmc;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(const std::string& m) { g_err = m; return 1; }
+
+#define HIPCHK(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(std::string(#expr) + ": " + hipGetErrorString(e_) + " (" + __FILE__ + \
+                        ":" + std::to_string(__LINE__) + ")");                              \
+    } while (0)
+#define CHK(expr) do { if (int rc_ = (expr)) return rc_; } while (0)
+
+int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
+int round_up(int n, int m) { return (n + m - 1) / m * m; }
+
+// ---- RCCL, loaded on demand -----------------------------------------------------------
+struct Rccl {
+    void* so = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+} g_rccl;
+
+int load_rccl()
+{
+    if (g_rccl.so) return 0;
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void* so = nullptr;
+    for (const char* n : names) if ((so = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!so) return fail(std::string("cannot load librccl.so: ") + dlerror());
+#define SYM(field, name)                                                         \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(so, name));    \
+    if (!g_rccl.field) return fail(std::string("librccl.so lacks ") + name);
+    SYM(GetUniqueId, "ncclGetUniqueId")
+    SYM(CommInitRank, "ncclCommInitRank")
+    SYM(CommDestroy, "ncclCommDestroy")
+    SYM(AllGather, "ncclAllGather")
+    SYM(Send, "ncclSend")
+    SYM(Recv, "ncclRecv")
+    SYM(GroupStart, "ncclGroupStart")
+    SYM(GroupEnd, "ncclGroupEnd")
+    SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    g_rccl.so = so;
+    return 0;
+}
+#define NCCLCHK(expr)                                                                             \
+    do {                                                                                          \
+        ncclResult_t r_ = (expr);                                                                 \
+        if (r_ != ncclSuccess)                                                                    \
+            return fail(std::string(#expr) + ": " + g_rccl.GetErrorString(r_));                   \
+    } while (0)
+
+// ---- handle ---------------------------------------------------------------------------
+struct Slab {
+    SlabView v{};
+    uint8_t* prev = nullptr;
+    double* Tbuf[2] = {nullptr, nullptr};
+    size_t nS = 0, nT = 0;   // bytes of a u8 array, doubles of an f64 array
+};
+
+struct Handle {
+    cetkmc_params p{};
+    KParams kp{};
+    int L = 0, Pk = 1, PB = 1, RJ = 0, pitchS = 0, pitchT = 0;
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    std::vector<Slab> slabs;
+    SlabView* d_views[2] = {nullptr, nullptr};   // per T-buffer parity
+    int cur = 0;                                 // current T buffer
+    int G = 1, my_first = 0;                     // global slab count, index of first local slab
+    int own_i0 = 0, own_i1 = 0;
+    BlockEnt* d_blocks = nullptr;
+    cetkmc_event* d_events_all = nullptr;
+    StepState* d_ss = nullptr;
+    double* d_ktab = nullptr;
+    void* d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+    int* d_flag = nullptr;
+    double* d_qtop = nullptr;
+    // batch buffers
+    double *d_u_pick = nullptr, *d_u_defect = nullptr, *d_u_np = nullptr, *d_q = nullptr, *d_log_total = nullptr;
+    cetkmc_event* d_log_event = nullptr;
+    int64_t* d_log_nev = nullptr;
+    size_t cap_steps = 0, cap_np = 0, cap_q = 0;
+    // rccl
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+    bool swept = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> prof;
+};
+
+KParams make_kparams(const cetkmc_params& p)
+{
+    KParams k{};
+    k.nu = p.nu; k.nu_dep = p.nu_dep;
+    for (int a = 0; a < 3; ++a) { k.E_b[a] = p.E_b[a]; k.E_diff[a] = p.E_diff[a]; }
+    k.kT = p.kT; k.T_melt = p.T_melt; k.I0 = p.I0; k.delta_T_c = p.delta_T_c;
+    k.rate_threshold = p.rate_threshold; k.anisotropy = p.anisotropy;
+    k.impurity_re = p.impurity_re; k.impurity_c = p.impurity_c;
+    k.K_nuc = p.K_nuc; k.beta_imp_nuc = p.beta_imp_nuc; k.max_imp_frac = p.max_imp_frac;
+    return k;
+}
+
+// kmc_event_rates.py:126-128, same expression order as the device helper k_eff()
+double host_k_eff(const cetkmc_params& p, int n_nb, int n_imp)
+{
+    int den = n_nb > 1 ? n_nb : 1;
+    double x = (double)n_imp / (double)den;
+    double f_imp = (x < p.max_imp_frac) ? x : p.max_imp_frac;
+    double K = p.K_nuc * (1.0 - p.beta_imp_nuc * f_imp);
+    double m = (K < p.K_nuc) ? K : p.K_nuc;
+    double lo = 0.1 * p.K_nuc;
+    return (m > lo) ? m : lo;
+}
+
+int upload_ktab(Handle* h)
+{
+    double tab[225];
+    for (int a = 0; a < 15; ++a)
+        for (int b = 0; b < 15; ++b) tab[a * 15 + b] = host_k_eff(h->p, a, b);
+    HIPCHK(hipMemcpyAsync(h->d_ktab, tab, sizeof tab, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int push_views(Handle* h)
+{
+    for (int par = 0; par < 2; ++par) {
+        std::vector<SlabView> v;
+        for (auto& s : h->slabs) { SlabView x = s.v; x.T = s.Tbuf[par]; v.push_back(x); }
+        HIPCHK(hipMemcpyAsync(h->d_views[par], v.data(), v.size() * sizeof(SlabView), hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int ensure_scratch(Handle* h, size_t bytes)
+{
+    if (bytes <= h->scratch_bytes) return 0;
+    if (h->d_scratch) HIPCHK(hipFree(h->d_scratch));
+    h->d_scratch = nullptr; h->scratch_bytes = 0;
+    HIPCHK(hipMalloc(&h->d_scratch, bytes));
+    h->scratch_bytes = bytes;
+    return 0;
+}
+
+int create_common(const cetkmc_params* p, int L, const std::vector<std::pair<int, int>>& ranges, int dev,
+                  int G, int my_first, void** out)
+{
+    if (!p || !out) return fail("null argument");
+    if (L < 1) return fail("L must be >= 1");
+    if (3 * L > PMAX) return fail("L too large for this build (3L <= " + std::to_string(PMAX) + ")");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail("no usable HIP device: libcetkmc_hip has no CPU fallback");
+    if (dev < 0 || dev >= ndev) return fail("device id out of range");
+    HIPCHK(hipSetDevice(dev));
+    Handle* h = new Handle();
+    h->p = *p; h->kp = make_kparams(*p);
+    h->L = L; h->Pk = next_pow2(L); h->PB = next_pow2(3 * L);
+    h->RJ = round_up(L, SWEEP_TJ) + 4;
+    h->pitchS = round_up(KOFF + L + 4, 16);
+    h->pitchT = round_up(L, 2);
+    h->dev = dev; h->G = G; h->my_first = my_first;
+    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&h->ev0));
+    HIPCHK(hipEventCreate(&h->ev1));
+    h->own_i0 = ranges.front().first;
+    h->own_i1 = ranges.back().first + ranges.back().second;
+    for (auto& r : ranges) {
+        Slab s;
+        s.v.L = L; s.v.gi0 = r.first; s.v.nloc = r.second;
+        s.v.RJ = h->RJ; s.v.pitchS = h->pitchS; s.v.pitchT = h->pitchT; s.v.Pk = h->Pk;
+        s.nS = (size_t)(r.second + 4) * h->RJ * h->pitchS;
+        s.nT = (size_t)(r.second + 4) * L * h->pitchT;
+        HIPCHK(hipMalloc((void**)&s.v.state, s.nS));
+        HIPCHK(hipMalloc((void**)&s.v.defects, s.nS));
+        HIPCHK(hipMalloc((void**)&s.prev, s.nS));
+        HIPCHK(hipMemsetAsync(s.v.state, OOB, s.nS, h->stream));
+        HIPCHK(hipMemsetAsync(s.v.defects, 0, s.nS, h->stream));
+        HIPCHK(hipMemsetAsync(s.prev, OOB, s.nS, h->stream));
+        for (int b = 0; b < 2; ++b) {
+            HIPCHK(hipMalloc((void**)&s.Tbuf[b], s.nT * sizeof(double)));
+            HIPCHK(hipMemsetAsync(s.Tbuf[b], 0, s.nT * sizeof(double), h->stream));
+        }
+        s.v.T = s.Tbuf[0];
+        HIPCHK(hipMalloc((void**)&s.v.theta, s.nT * sizeof(double)));
+        HIPCHK(hipMalloc((void**)&s.v.phi, s.nT * sizeof(double)));
+        HIPCHK(hipMemsetAsync(s.v.theta, 0, s.nT * sizeof(double), h->stream));
+        HIPCHK(hipMemsetAsync(s.v.phi, 0, s.nT * sizeof(double), h->stream));
+        HIPCHK(hipMalloc((void**)&s.v.rowsum, (size_t)r.second * 3 * L * sizeof(double)));
+        HIPCHK(hipMalloc((void**)&s.v.rowcnt, (size_t)r.second * 3 * L * sizeof(int32_t)));
+        HIPCHK(hipMemsetAsync(s.v.rowsum, 0, (size_t)r.second * 3 * L * sizeof(double), h->stream));
+        HIPCHK(hipMemsetAsync(s.v.rowcnt, 0, (size_t)r.second * 3 * L * sizeof(int32_t), h->stream));
+        h->slabs.push_back(s);
+    }
+    for (int par = 0; par < 2; ++par) HIPCHK(hipMalloc((void**)&h->d_views[par], h->slabs.size() * sizeof(SlabView)));
+    HIPCHK(hipMalloc((void**)&h->d_blocks, (size_t)PMAX * sizeof(BlockEnt)));
+    HIPCHK(hipMemsetAsync(h->d_blocks, 0, (size_t)PMAX * sizeof(BlockEnt), h->stream));
+    HIPCHK(hipMalloc((void**)&h->d_events_all, (size_t)G * sizeof(cetkmc_event)));
+    HIPCHK(hipMemsetAsync(h->d_events_all, 0xFF, (size_t)G * sizeof(cetkmc_event), h->stream));   // type = -1
+    HIPCHK(hipMalloc((void**)&h->d_ss, sizeof(StepState)));
+    HIPCHK(hipMemsetAsync(h->d_ss, 0, sizeof(StepState), h->stream));
+    HIPCHK(hipMalloc((void**)&h->d_ktab, 225 * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&h->d_flag, sizeof(int)));
+    HIPCHK(hipMalloc((void**)&h->d_qtop, (size_t)L * L * sizeof(double)));
+    CHK(upload_ktab(h));
+    CHK(push_views(h));
+    *out = h;
+    return 0;
+}
+
+SlabView view_of(Handle* h, int s) { SlabView v = h->slabs[s].v; v.T = h->slabs[s].Tbuf[h->cur]; return v; }
+
+// extended (owned + halo, clipped) global plane range of a slab
+void ext_range(const Handle* h, const Slab& s, int* a, int* b)
+{
+    *a = std::max(0, s.v.gi0 - 2);
+    *b = std::min(h->L, s.v.gi0 + s.v.nloc + 2);
+}
+
+// f64 field: host contiguous planes [i_begin,..) -> pitched device array, planes [a,b)
+int h2d_f64(Handle* h, const Slab& s, double* dst, const double* src, int i_begin, int a, int b)
+{
+    const int L = h->L;
+    const int li = a - (s.v.gi0 - 2);
+    HIPCHK(hipMemcpy2DAsync(dst + (size_t)li * L * h->pitchT, (size_t)h->pitchT * 8,
+                            src + (size_t)(a - i_begin) * L * L, (size_t)L * 8, (size_t)L * 8,
+                            (size_t)(b - a) * L, hipMemcpyHostToDevice, h->stream));
+    return 0;
+}
+int d2h_f64(Handle* h, const Slab& s, const double* srcd, double* dst, int i_begin, int a, int b)
+{
+    const int L = h->L;
+    const int li = a - (s.v.gi0 - 2);
+    HIPCHK(hipMemcpy2DAsync(dst + (size_t)(a - i_begin) * L * L, (size_t)L * 8,
+                            srcd + (size_t)li * L * h->pitchT, (size_t)h->pitchT * 8, (size_t)L * 8,
+                            (size_t)(b - a) * L, hipMemcpyDeviceToHost, h->stream));
+    return 0;
+}
+
+template <class SRC>
+int h2d_u8(Handle* h, const Slab& s, uint8_t* dst, const SRC* src, int i_begin, int a, int b, bool check)
+{
+    const int L = h->L;
+    const size_t n = (size_t)(b - a) * L * L;
+    CHK(ensure_scratch(h, n * sizeof(SRC)));
+    HIPCHK(hipMemcpyAsync(h->d_scratch, src + (size_t)(a - i_begin) * L * L, n * sizeof(SRC), hipMemcpyHostToDevice, h->stream));
+    const int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+    if (check) {
+        if constexpr (sizeof(SRC) == 8) {
+            HIPCHK(hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
+            hipLaunchKernelGGL(k_check_range, dim3(grid), dim3(256), 0, h->stream, (const int64_t*)h->d_scratch, (int64_t)n, 0, 127, h->d_flag);
+            int bad = 0;
+            HIPCHK(hipMemcpyAsync(&bad, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            if (bad) return fail("state/defects values must lie in 0..127");
+        }
+    }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pack_u8<SRC>), dim3(grid), dim3(256), 0, h->stream, s.v, dst, (const SRC*)h->d_scratch, a, b - a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));   // scratch is reused by the next field
+    return 0;
+}
+template <class DST>
+int d2h_u8(Handle* h, const Slab& s, const uint8_t* srcd, DST* dst, int i_begin, int a, int b)
+{
+    const int L = h->L;
+    const size_t n = (size_t)(b - a) * L * L;
+    CHK(ensure_scratch(h, n * sizeof(DST)));
+    const int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_unpack_u8<DST>), dim3(grid), dim3(256), 0, h->stream, s.v, srcd, (DST*)h->d_scratch, a, b - a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(dst + (size_t)(a - i_begin) * L * L, h->d_scratch, n * sizeof(DST), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+template <class I>
+int upload_impl(Handle* h, int i_begin, int i_end, const I* state, const double* theta, const double* phi,
+                const double* T, const I* defects)
+{
+    HIPCHK(hipSetDevice(h->dev));
+    for (auto& s : h->slabs) {
+        int a, b;
+        ext_range(h, s, &a, &b);
+        if (a < i_begin || b > i_end) return fail("upload range does not cover the slab's planes + halo");
+        if (state) {
+            CHK(h2d_u8<I>(h, s, s.v.state, state, i_begin, a, b, true));
+            HIPCHK(hipMemcpyAsync(s.prev, s.v.state, s.nS, hipMemcpyDeviceToDevice, h->stream));
+        }
+        if (defects) CHK(h2d_u8<I>(h, s, s.v.defects, defects, i_begin, a, b, true));
+        if (theta) CHK(h2d_f64(h, s, s.v.theta, theta, i_begin, a, b));
+        if (phi) CHK(h2d_f64(h, s, s.v.phi, phi, i_begin, a, b));
+        if (T) CHK(h2d_f64(h, s, s.Tbuf[h->cur], T, i_begin, a, b));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->swept = false;
+    return 0;
+}
+template <class I>
+int download_impl(Handle* h, int i_begin, int i_end, I* state, double* theta, double* phi, double* T, I* defects)
+{
+    HIPCHK(hipSetDevice(h->dev));
+    for (auto& s : h->slabs) {
+        int a = std::max(s.v.gi0, i_begin), b = std::min(s.v.gi0 + s.v.nloc, i_end);
+        if (a >= b) continue;
+        if (state) CHK(d2h_u8<I>(h, s, s.v.state, state, i_begin, a, b));
+        if (defects) CHK(d2h_u8<I>(h, s, s.v.defects, defects, i_begin, a, b));
+        if (theta) CHK(d2h_f64(h, s, s.v.theta, theta, i_begin, a, b));
+        if (phi) CHK(d2h_f64(h, s, s.v.phi, phi, i_begin, a, b));
+        if (T) CHK(d2h_f64(h, s, s.Tbuf[h->cur], T, i_begin, a, b));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ---- per-step launches (all asynchronous on h->stream) -----------------------------------
+int launch_sweep(Handle* h, bool batch)
+{
+    const int TR = SWEEP_TJ + 4;
+    const size_t shmem = (size_t)((5 * TR * h->pitchS + 15) & ~15) + 225 * sizeof(double);
+    const StepState* ss = batch ? h->d_ss : nullptr;
+    for (size_t s = 0; s < h->slabs.size(); ++s) {
+        SlabView v = view_of(h, (int)s);
+        const int njt = (h->L + SWEEP_TJ - 1) / SWEEP_TJ;
+        hipLaunchKernelGGL(k_sweep, dim3(v.nloc * njt), dim3(256), shmem, h->stream, h->kp, v, h->d_ktab, ss);
+        hipLaunchKernelGGL(k_plane_reduce, dim3(3 * v.nloc), dim3(64), 0, h->stream, v, h->d_blocks, ss);
+    }
+    HIPCHK(hipGetLastError());
+    if (h->nranks > 1) {
+        const size_t per = (size_t)3 * (h->L / h->nranks) * sizeof(BlockEnt);
+        NCCLCHK(g_rccl.AllGather((const char*)h->d_blocks + per * h->rank, h->d_blocks, per, ncclChar, h->comm, h->stream));
+    }
+    h->swept = true;
+    return 0;
+}
+
+int launch_select(Handle* h, const BatchCfg& cfg, double r_direct, int info_only)
+{
+    hipLaunchKernelGGL(k_select, dim3(1), dim3(256), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
+                       (int)h->slabs.size(), h->L, h->PB, (const BlockEnt*)h->d_blocks, h->d_ss, cfg,
+                       (const double*)h->d_u_pick, r_direct, (const double*)h->d_ktab,
+                       h->d_events_all + h->my_first, info_only);
+    HIPCHK(hipGetLastError());
+    if (h->nranks > 1 && !info_only) {
+        NCCLCHK(g_rccl.AllGather((const char*)(h->d_events_all + h->rank), h->d_events_all, sizeof(cetkmc_event),
+                                 ncclChar, h->comm, h->stream));
+    }
+    return 0;
+}
+
+int exchange_T_halo(Handle* h, int buf)
+{
+    const size_t plane = (size_t)h->L * h->pitchT;   // doubles
+    for (size_t s = 0; s + 1 < h->slabs.size(); ++s) {
+        Slab& a = h->slabs[s];
+        Slab& b = h->slabs[s + 1];
+        // a's top two owned planes -> b's lower halo; b's bottom two owned planes -> a's upper halo
+        HIPCHK(hipMemcpyAsync(b.Tbuf[buf], a.Tbuf[buf] + plane * a.v.nloc, 2 * plane * 8, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(a.Tbuf[buf] + plane * (a.v.nloc + 2), b.Tbuf[buf] + plane * 2, 2 * plane * 8, hipMemcpyDeviceToDevice, h->stream));
+    }
+    if (h->nranks > 1) {
+        Slab& s = h->slabs[0];
+        double* T = s.Tbuf[buf];
+        const size_t cnt = 2 * plane * 8;
+        NCCLCHK(g_rccl.GroupStart());
+        if (h->rank > 0) {
+            NCCLCHK(g_rccl.Send(T + plane * 2, cnt, ncclChar, h->rank - 1, h->comm, h->stream));
+            NCCLCHK(g_rccl.Recv(T, cnt, ncclChar, h->rank - 1, h->comm, h->stream));
+        }
+        if (h->rank < h->nranks - 1) {
+            NCCLCHK(g_rccl.Send(T + plane * s.v.nloc, cnt, ncclChar, h->rank + 1, h->comm, h->stream));
+            NCCLCHK(g_rccl.Recv(T + plane * (s.v.nloc + 2), cnt, ncclChar, h->rank + 1, h->comm, h->stream));
+        }
+        NCCLCHK(g_rccl.GroupEnd());
+    }
+    return 0;
+}
+
+int launch_thermal(Handle* h, double dt, int laser, const double* d_q, int use_latent, int scrub, bool batch)
+{
+    ThermalCfg C{};
+    C.dt = dt; C.alpha = h->p.alpha; C.inv_dx2 = h->p.inv_dx2; C.clip_lo = h->p.T_clip_lo; C.clip_hi = h->p.T_clip_hi;
+    C.T_nan = h->p.T_nan; C.rho_cp = h->p.rho_cp; C.latent_coef = h->p.latent_coef;
+    C.laser = laser; C.use_latent = use_latent; C.scrub = scrub;
+    const int nxt = h->cur ^ 1;
+    for (size_t s = 0; s < h->slabs.size(); ++s) {
+        SlabView v = view_of(h, (int)s);
+        dim3 grid((h->L + 255) / 256, h->L, v.nloc);
+        hipLaunchKernelGGL(k_thermal, grid, dim3(256), 0, h->stream, v, (const double*)h->slabs[s].Tbuf[h->cur],
+                           h->slabs[s].Tbuf[nxt], (const uint8_t*)h->slabs[s].prev, d_q, C,
+                           batch ? (const StepState*)h->d_ss : nullptr);
+    }
+    HIPCHK(hipGetLastError());
+    CHK(exchange_T_halo(h, nxt));
+    if (laser && use_latent)
+        for (auto& s : h->slabs) HIPCHK(hipMemcpyAsync(s.prev, s.v.state, s.nS, hipMemcpyDeviceToDevice, h->stream));
+    h->cur = nxt;
+    h->swept = false;
+    return 0;
+}
+
+template <class T>
+int grow(T** p, size_t* cap, size_t need)
+{
+    if (need <= *cap && *p) return 0;
+    if (*p) HIPCHK(hipFree(*p));
+    *p = nullptr;
+    size_t n = std::max<size_t>(need, 16);
+    HIPCHK(hipMalloc((void**)p, n * sizeof(T)));
+    *cap = n;
+    return 0;
+}
+
+void destroy_impl(Handle* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->dev);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    for (auto& s : h->slabs) {
+        (void)hipFree(s.v.state); (void)hipFree(s.v.defects); (void)hipFree(s.prev);
+        (void)hipFree(s.Tbuf[0]); (void)hipFree(s.Tbuf[1]); (void)hipFree(s.v.theta); (void)hipFree(s.v.phi);
+        (void)hipFree(s.v.rowsum); (void)hipFree(s.v.rowcnt);
+    }
+    void* ptrs[] = {h->d_views[0], h->d_views[1], h->d_blocks, h->d_events_all, h->d_ss, h->d_ktab, h->d_scratch,
+                    h->d_flag, h->d_qtop, h->d_u_pick, h->d_u_defect, h->d_u_np, h->d_q, h->d_log_total,
+                    h->d_log_event, h->d_log_nev};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto e : h->prof) (void)hipEventDestroy(e);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+}  // namespace
+
+// =========================================================================================
+extern "C" {
+
+const char* cetkmc_last_error(void) { return g_err.c_str(); }
+int cetkmc_abi_version(void) { return CETKMC_ABI_VERSION; }
+
+int cetkmc_device_count(int* n)
+{
+    if (!n) return fail("null argument");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *n = 0; return fail(std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+    *n = c;
+    return 0;
+}
+
+int cetkmc_create(const cetkmc_params* p, int L, int n_slabs, const int* device_ids, void** handle)
+{
+    if (n_slabs < 1) return fail("n_slabs must be >= 1");
+    int dev = device_ids ? device_ids[0] : 0;
+    for (int s = 1; s < n_slabs && device_ids; ++s)
+        if (device_ids[s] != dev)
+            return fail("in-process slabs must share one device; multi-GPU runs use one process per GPU (cetkmc_create_rank)");
+    if (n_slabs > 1 && L / n_slabs < 2) return fail("each slab needs at least 2 planes");
+    std::vector<std::pair<int, int>> ranges;
+    int base = L / n_slabs, rem = L % n_slabs, at = 0;
+    for (int s = 0; s < n_slabs; ++s) { int n = base + (s < rem ? 1 : 0); ranges.push_back({at, n}); at += n; }
+    return create_common(p, L, ranges, dev, n_slabs, 0, handle);
+}
+
+int cetkmc_get_unique_id(char out[128])
+{
+    CHK(load_rccl());
+    ncclUniqueId id;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    NCCLCHK(g_rccl.GetUniqueId(&id));
+    memcpy(out, &id, 128);
+    return 0;
+}
+
+int cetkmc_create_rank(const cetkmc_params* p, int L, int rank, int nranks, int device_id, const char unique_id[128],
+                       void** handle)
+{
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail("bad rank/nranks");
+    if (L % nranks != 0) return fail("L must be divisible by the number of ranks");
+    if (nranks > 1 && L / nranks < 2) return fail("each slab needs at least 2 planes");
+    const int n = L / nranks;
+    std::vector<std::pair<int, int>> ranges{{rank * n, n}};
+    CHK(create_common(p, L, ranges, device_id, nranks, rank, handle));
+    Handle* h = (Handle*)*handle;
+    h->rank = rank; h->nranks = nranks;
+    if (nranks > 1 || unique_id) {
+        if (!unique_id) { destroy_impl(h); *handle = nullptr; return fail("unique_id required"); }
+        if (load_rccl()) { destroy_impl(h); *handle = nullptr; return 1; }
+        ncclUniqueId id;
+        memcpy(&id, unique_id, 128);
+        ncclResult_t r = g_rccl.CommInitRank(&h->comm, nranks, id, rank);
+        if (r != ncclSuccess) {
+            std::string m = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r);
+            destroy_impl(h); *handle = nullptr;
+            return fail(m);
+        }
+    }
+    return 0;
+}
+
+int cetkmc_destroy(void* handle) { destroy_impl((Handle*)handle); return 0; }
+
+int cetkmc_set_params(void* handle, const cetkmc_params* p)
+{
+    Handle* h = (Handle*)handle;
+    if (!h || !p) return fail("null argument");
+    HIPCHK(hipSetDevice(h->dev));
+    h->p = *p; h->kp = make_kparams(*p);
+    h->swept = false;
+    return upload_ktab(h);
+}
+
+int cetkmc_sync(void* handle)
+{
+    Handle* h = (Handle*)handle;
+    if (!h) return fail("null handle");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int cetkmc_owned_planes(void* handle, int* i0, int* i1)
+{
+    Handle* h = (Handle*)handle;
+    if (!h) return fail("null handle");
+    if (i0) *i0 = h->own_i0;
+    if (i1) *i1 = h->own_i1;
+    return 0;
+}
+
+int cetkmc_upload(void* handle, const int64_t* state, const double* theta, const double* phi, const double* T,
+                  const int64_t* defects)
+{
+    Handle* h = (Handle*)handle;
+    if (!h) return fail("null handle");
+    return upload_impl<int64_t>(h, 0, h->L, state, theta, phi, T, defects);
+}
+int cetkmc_download(void* handle, int64_t* state, double* theta, double* phi, double* T, int64_t* defects)
+{
+    Handle* h = (Handle*)handle;
+    if (!h) return fail("null handle");
+    return download_impl<int64_t>(h, 0, h->L, state, theta, phi, T, defects);
+}
+int cetkmc_upload_planes(void* handle, int i_begin, int i_end, const uint8_t* state, const double* theta,
+                         const double* phi, const double* T, const uint8_t* defects)
+{
+    Handle* h = (Handle*)handle;
+    if (!h) return fail("null handle");
+    if (i_begin < 0 || i_end > h->L || i_begin >= i_end) return fail("bad plane range");
+    return upload_impl<uint8_t>(h, i_begin, i_end, state, theta, phi, T, defects);
+}
+int cetkmc_download_planes(void* handle, int i_begin, int i_end, uint8_t* state, double* theta, double* phi, double* T,
+                           uint8_t* defects)
+{
+    Handle* h = (Handle*)handle;
+    if (!h) return fail("null handle");
+    if (i_begin < 0 || i_end > h->L || i_begin >= i_end) return fail("bad plane range");
+    return download_impl<uint8_t>(h, i_begin, i_end, state, theta, phi, T, defects);
+}
+
+int cetkmc_set_defects(void* handle, const uint8_t* mask)
+{
+    Handle* h = (Handle*)handle;
+    if (!h || !mask) return fail("null argument");
+    HIPCHK(hipSetDevice(h->dev));
+    for (auto& s : h->slabs) {
+        int a, b;
+        ext_range(h, s, &a, &b);
+        CHK(h2d_u8<uint8_t>(h, s, s.v.defects, mask, 0, a, b, false));
+    }
+    h->swept = false;
+    return 0;
+}
+
+int cetkmc_set_prev_state(void* handle, const int64_t* prev_state)
+{
+    Handle* h = (Handle*)handle;
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->dev));
+    for (auto& s : h->slabs) {
+        if (prev_state) {
+            int a, b;
+            ext_range(h, s, &a, &b);
+            CHK(h2d_u8<int64_t>(h, s, s.prev, prev_state, 0, a, b, true));
+        } else {
+            HIPCHK(hipMemcpyAsync(s.prev, s.v.state, s.nS, hipMemcpyDeviceToDevice, h->stream));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int cetkmc_thermal_cet(void* handle, double dt, int scrub_nan)
+{
+    Handle* h = (Handle*)handle;
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->dev));
+    CHK(launch_thermal(h, dt, 0, nullptr, 0, scrub_nan, false));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int cetkmc_thermal_laser(void* handle, double dt, const double* q_top, int use_latent, int scrub_nan)
+{
+    Handle* h = (Handle*)handle;
+    if (!h || !q_top) return fail("null argument");
+    HIPCHK(hipSetDevice(h->dev));
+    HIPCHK(hipMemcpyAsync(h->d_qtop, q_top, (size_t)h->L * h->L * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    CHK(launch_thermal(h, dt, 1, h->d_qtop, use_latent, scrub_nan, false));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int cetkmc_rate_sweep(void* handle, cetkmc_sweep_info* info)
+{
+    Handle* h = (Handle*)handle;
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->dev));
+    CHK(launch_sweep(h, false));
+    BatchCfg cfg{};
+    CHK(launch_select(h, cfg, 0.0, 1));
+    StepState ss;
+    HIPCHK(hipMemcpyAsync(&ss, h->d_ss, sizeof ss, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (info) { info->total = ss.total; info->n_events = ss.n_events; info->n_dep = ss.n_dep; }
+    return 0;
+}
+
+int cetkmc_select(void* handle, double r, cetkmc_event* out)
+{
+    Handle* h = (Handle*)handle;
+    if (!h || !out) return fail("null argument");
+    if (!h->swept) return fail("cetkmc_select needs a preceding cetkmc_rate_sweep on the current lattice");
+    HIPCHK(hipSetDevice(h->dev));
+    BatchCfg cfg{};
+    CHK(launch_select(h, cfg, r, 0));
+    std::vector<cetkmc_event> all(h->G);
+    HIPCHK(hipMemcpyAsync(all.data(), h->d_events_all, all.size() * sizeof(cetkmc_event), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    out->type = -1;
+    for (auto& e : all) if (e.type >= 0) *out = e;
+    if (out->type < 0) return fail("no valid events");
+    return 0;
+}
+
+int cetkmc_apply(void* handle, const cetkmc_event* ev, double theta_new, double phi_new, int make_defect)
+{
+    Handle* h = (Handle*)handle;
+    if (!h || !ev) return fail("null argument");
+    if (ev->type < 0 || ev->type > 3) return fail("bad event type");
+    for (int a = 0; a < 3; ++a) if (ev->pos[a] < 0 || ev->pos[a] >= h->L) return fail("event position out of range");
+    if (ev->type == CETKMC_DIFF || ev->type == CETKMC_ATT)
+        for (int a = 0; a < 3; ++a) if (ev->target[a] < 0 || ev->target[a] >= h->L) return fail("event target out of range");
+    HIPCHK(hipSetDevice(h->dev));
+    cetkmc_event e = *ev;
+    if (e.type == CETKMC_DEP || e.type == CETKMC_NUC) { e.theta = theta_new; e.phi = phi_new; }
+    hipLaunchKernelGGL(k_apply_direct, dim3(1), dim3(64), 0, h->stream, (const SlabView*)h->d_views[h->cur],
+                       (int)h->slabs.size(), e, make_defect, h->d_ss);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->swept = false;
+    return 0;
+}
+
+int cetkmc_row_sums(void* handle, double* rowsum, int32_t* rowcnt)
+{
+    Handle* h = (Handle*)handle;
+    if (!h) return fail("null handle");
+    if (!h->swept) return fail("cetkmc_row_sums needs a preceding cetkmc_rate_sweep");
+    HIPCHK(hipSetDevice(h->dev));
+    const size_t L = h->L;
+    for (auto& s : h->slabs) {
+        const size_t off = (size_t)s.v.gi0 * 3 * L, n = (size_t)s.v.nloc * 3 * L;
+        if (rowsum) HIPCHK(hipMemcpyAsync(rowsum + off, s.v.rowsum, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (rowcnt) HIPCHK(hipMemcpyAsync(rowcnt + off, s.v.rowcnt, n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int cetkmc_enumerate_events(void* handle, cetkmc_event* buf, int64_t cap, int64_t* n)
+{
+    Handle* h = (Handle*)handle;
+    if (!h || !n) return fail("null argument");
+    HIPCHK(hipSetDevice(h->dev));
+    CHK(launch_sweep(h, false));
+    const size_t L = h->L;
+    int64_t total = 0;
+    std::vector<std::vector<int64_t>> offs(h->slabs.size());
+    for (size_t s = 0; s < h->slabs.size(); ++s) {
+        Slab& sl = h->slabs[s];
+        const size_t rows = (size_t)sl.v.nloc * 3 * L;
+        std::vector<int32_t> cnt(rows);
+        HIPCHK(hipMemcpyAsync(cnt.data(), sl.v.rowcnt, rows * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        offs[s].resize(rows);
+        for (size_t r = 0; r < rows; ++r) { offs[s][r] = total; total += cnt[r]; }
+    }
+    *n = total;
+    if (!buf || cap <= 0 || total == 0) return 0;
+    const int64_t m = std::min<int64_t>(cap, total);
+    cetkmc_event* d_out = nullptr;
+    HIPCHK(hipMalloc((void**)&d_out, (size_t)m * sizeof(cetkmc_event)));
+    for (size_t s = 0; s < h->slabs.size(); ++s) {
+        const size_t rows = offs[s].size();
+        int64_t* d_off = nullptr;
+        HIPCHK(hipMalloc((void**)&d_off, rows * sizeof(int64_t)));
+        HIPCHK(hipMemcpyAsync(d_off, offs[s].data(), rows * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_enumerate, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, h->stream, h->kp, view_of(h, (int)s),
+                           (const double*)h->d_ktab, (const int64_t*)d_off, d_out, m);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipFree(d_off));
+    }
+    HIPCHK(hipMemcpy(buf, d_out, (size_t)m * sizeof(cetkmc_event), hipMemcpyDeviceToHost));
+    HIPCHK(hipFree(d_out));
+    int64_t rank = 0;
+    for (int64_t e = 0; e < m; ++e) if (buf[e].type == CETKMC_DEP) buf[e].dep_rank = rank++;
+    return 0;
+}
+
+int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* res, double* totals,
+                     cetkmc_event* events, int64_t* n_events)
+{
+    Handle* h = (Handle*)handle;
+    if (!h || !a || !res) return fail("null argument");
+    const int64_t n = a->n_steps;
+    if (n < 0) return fail("n_steps < 0");
+    if (n > 0 && !a->u_pick) return fail("u_pick required");
+    if (a->defect_fraction > 0.0 && n > 0 && !a->u_defect) return fail("u_defect required when defect_fraction > 0");
+    if (a->np_cap > 0 && !a->u_np) return fail("u_np required");
+    int64_t n_therm = 0;
+    if (a->thermal_mode) for (int64_t s = 0; s < n; ++s) if ((a->step0 + s) % 20 == 0) ++n_therm;
+    if (a->thermal_mode == 2 && (n_therm > a->n_q || (n_therm > 0 && !a->q_planes)))
+        return fail("thermal_mode 2 needs one q plane per thermal update in the batch");
+    HIPCHK(hipSetDevice(h->dev));
+    const size_t L2 = (size_t)h->L * h->L;
+    {
+        size_t c1 = h->cap_steps, c2 = h->cap_steps, c3 = h->cap_steps, c4 = h->cap_steps, c5 = h->cap_steps;
+        CHK(grow(&h->d_u_pick, &c1, (size_t)n));
+        CHK(grow(&h->d_u_defect, &c2, (size_t)n));
+        CHK(grow(&h->d_log_total, &c3, (size_t)n));
+        CHK(grow(&h->d_log_event, &c4, (size_t)n));
+        CHK(grow(&h->d_log_nev, &c5, (size_t)n));
+        h->cap_steps = std::min({c1, c2, c3, c4, c5});
+        CHK(grow(&h->d_u_np, &h->cap_np, (size_t)std::max<int64_t>(a->np_cap, 2)));
+        if (a->thermal_mode == 2) CHK(grow(&h->d_q, &h->cap_q, (size_t)std::max<int64_t>(n_therm, 1) * L2));
+    }
+    if (n > 0) HIPCHK(hipMemcpyAsync(h->d_u_pick, a->u_pick, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+    if (n > 0 && a->u_defect) HIPCHK(hipMemcpyAsync(h->d_u_defect, a->u_defect, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+    if (a->np_cap > 0) HIPCHK(hipMemcpyAsync(h->d_u_np, a->u_np, (size_t)a->np_cap * 8, hipMemcpyHostToDevice, h->stream));
+    if (a->thermal_mode == 2 && n_therm > 0)
+        HIPCHK(hipMemcpyAsync(h->d_q, a->q_planes, (size_t)n_therm * L2 * 8, hipMemcpyHostToDevice, h->stream));
+    // reset the batch part of the step state (nucleation_count persists)
+    StepState ss;
+    HIPCHK(hipMemcpyAsync(&ss, h->d_ss, sizeof ss, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    ss.cur = 0; ss.status = 0; ss.np_pos = 0; ss.q_pos = 0;
+    HIPCHK(hipMemcpyAsync(h->d_ss, &ss, sizeof ss, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+
+    BatchCfg cfg{};
+    cfg.step0 = a->step0; cfg.np_cap = a->np_cap; cfg.defect_fraction = a->defect_fraction; cfg.seed = a->seed;
+    cfg.rng_mode = a->rng_mode; cfg.batch = 1;
+    if (a->profile) {
+        while ((int64_t)h->prof.size() < 2 * n) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->prof.push_back(e); }
+    }
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    int64_t q_idx = 0;
+    for (int64_t s = 0; s < n; ++s) {
+        const int64_t g = a->step0 + s;
+        if (a->thermal_mode && g % 20 == 0) {
+            if (a->thermal_mode == 1) CHK(launch_thermal(h, a->thermal_dt, 0, nullptr, 0, 1, true));
+            else { CHK(launch_thermal(h, a->thermal_dt, 1, h->d_q + (size_t)q_idx * L2, a->use_latent, 1, true)); ++q_idx; }
+        }
+        if (a->profile) HIPCHK(hipEventRecord(h->prof[2 * s], h->stream));
+        CHK(launch_sweep(h, true));
+        if (a->profile) HIPCHK(hipEventRecord(h->prof[2 * s + 1], h->stream));
+        CHK(launch_select(h, cfg, 0.0, 0));
+        hipLaunchKernelGGL(k_apply_batch, dim3(1), dim3(64), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
+                           (int)h->slabs.size(), h->L, (const cetkmc_event*)h->d_events_all, h->G, h->d_ss, cfg,
+                           (const double*)h->d_u_defect, (const double*)h->d_u_np, h->d_log_total, h->d_log_event,
+                           h->d_log_nev);
+        h->swept = false;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipMemcpyAsync(&ss, h->d_ss, sizeof ss, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    res->steps_done = ss.cur; res->status = ss.status; res->np_used = ss.np_pos; res->q_used = q_idx;
+    res->nucleation_count = ss.nuc_count;
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    res->wall_ms = ms;
+    res->sweep_ms_total = 0.0; res->sweep_launches = 0;
+    if (a->profile) {
+        for (int64_t s = 0; s < n; ++s) {
+            float t = 0.f;
+            HIPCHK(hipEventElapsedTime(&t, h->prof[2 * s], h->prof[2 * s + 1]));
+            res->sweep_ms_total += t;
+        }
+        res->sweep_launches = n;
+    }
+    const int64_t done = ss.cur;
+    const int64_t nt = done + (ss.status == 1 ? 1 : 0);
+    if (totals && done > 0) HIPCHK(hipMemcpy(totals, h->d_log_total, (size_t)done * 8, hipMemcpyDeviceToHost));
+    if (totals && ss.status == 1 && nt <= n) totals[done] = ss.total;
+    if (events && done > 0) HIPCHK(hipMemcpy(events, h->d_log_event, (size_t)done * sizeof(cetkmc_event), hipMemcpyDeviceToHost));
+    if (n_events && done > 0) HIPCHK(hipMemcpy(n_events, h->d_log_nev, (size_t)done * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int64_t cetkmc_nucleation_count(void* handle)
+{
+    Handle* h = (Handle*)handle;
+    if (!h) return -1;
+    StepState ss;
+    if (hipSetDevice(h->dev) != hipSuccess) return -1;
+    if (hipMemcpy(&ss, h->d_ss, sizeof ss, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return ss.nuc_count;
+}
+
+int cetkmc_reset_counters(void* handle)
+{
+    Handle* h = (Handle*)handle;
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->dev));
+    HIPCHK(hipMemsetAsync(h->d_ss, 0, sizeof(StepState), h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int cetkmc_time_sweeps(void* handle, int n, double* ms_total)
+{
+    Handle* h = (Handle*)handle;
+    if (!h || !ms_total) return fail("null argument");
+    HIPCHK(hipSetDevice(h->dev));
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    for (int s = 0; s < n; ++s) CHK(launch_sweep(h, false));
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *ms_total = ms;
+    return 0;
+}
+
+}  // extern "C"

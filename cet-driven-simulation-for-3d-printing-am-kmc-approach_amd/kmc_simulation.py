@@ -1,0 +1,189 @@
+"""Rejection-free KMC stepping loop on the GPU (drop-in for the reference ``kmc_simulation.py``).
+
+``run_kmc`` keeps the reference's signature, return tuple, prints and ``metrics.csv`` contract
+(kmc_simulation.py:203-398).  The hot loop -- thermal update every 20 steps, full-lattice rate
+sweep, cumulative-rate event pick, lattice update -- runs on the device in batches through
+``cetkmc_run_steps`` with NO host round trip per step; the host only
+
+  * pre-draws the random streams from the very generators the reference uses (CPython
+    ``random`` for the pick / defect / time draws, NumPy's legacy global stream for the
+    deposition-species and orientation draws) and afterwards rewinds them to exactly the
+    position the reference would have reached, and
+  * runs the analysis that is not part of the hot path (defect-mask refresh and metrics every
+    ``METRIC_UPDATE_STEP`` steps).
+
+There is no CPU fallback; without libcetkmc_hip.so + a GPU this raises.
+"""
+import os
+import random
+
+import numpy as np
+import pandas as pd
+
+from constants import (ATOMIC_SPACING_W, CET_CHECK_INTERVAL, DEFECT_ID, LATTICE_SIZE,  # noqa: F401
+                       METRIC_UPDATE_STEP, N_STEPS, NU_DEP, RANDOM_SEED, RATE_THRESHOLD, T_MELT, T_SUB,
+                       VOXEL_SIZE)
+from defects import introduce_defects
+from kmc_event_rates import get_event_rates  # noqa: F401  (re-exported like the reference)
+from lattice_init import initialize_lattice
+from metrics import compute_CET, compute_metrics, detect_CET_transition
+from thermal_solver import update_temperature_cet as update_temperature  # noqa: F401
+
+THERMAL_EVERY = 20          # kmc_simulation.py:248
+THERMAL_DT = 1e-6           # kmc_simulation.py:250
+_MAX_STREAM_DOUBLES = 1 << 25   # host staging cap for the pre-drawn NumPy stream (256 MiB)
+
+
+def _advance_to(engine, first, last, L, defect_fraction, rng_mode=0, seed=0):
+    """Run steps first..last (inclusive) on the device.  Returns (steps_done, terminated,
+    last_total, dt_sum_increments) with both host generators left where the reference's would be."""
+    dts = []
+    step = first
+    terminated = False
+    last_total = 0.0
+    per = 3 if defect_fraction > 0.0 else 2
+    while step <= last:
+        n = last - step + 1
+        per_step = (L * L + 2) if rng_mode == 0 else 2
+        n = max(1, min(n, _MAX_STREAM_DOUBLES // per_step))
+        py_state = random.getstate()
+        draws = np.array([random.random() for _ in range(per * n)], dtype=np.float64).reshape(n, per)
+        np_state = np.random.get_state()
+        u_np = np.random.random(n * per_step)
+        res = engine.run_steps(step, n, defect_fraction, draws[:, 0], draws[:, 1] if per == 3 else None, u_np,
+                               rng_mode=rng_mode, seed=seed, thermal_mode=1, thermal_dt=THERMAL_DT)
+        done = res["done"]
+        # rewind both generators to what the executed steps consumed
+        np.random.set_state(np_state)
+        if res["np_used"]:
+            np.random.random(res["np_used"])
+        if done < n:
+            random.setstate(py_state)
+            for _ in range(per * done):
+                random.random()
+        for s in range(done):
+            total = res["totals"][s]
+            dts.append(max(-np.log(max(1e-12, draws[s, per - 1])) / total, 1e-12))   # kmc_simulation.py:331
+        step += done
+        if res["status"] == 1:
+            terminated = True
+            last_total = float(res["totals"][done]) if len(res["totals"]) > done else 0.0
+            break
+        if res["status"] == 2 and done == 0:
+            raise RuntimeError("pre-drawn NumPy stream too small for a single step")
+    return step - first, terminated, last_total, dts
+
+
+def run_kmc(
+    L: int = LATTICE_SIZE,
+    n_steps: int = N_STEPS,
+    temp: float = T_SUB,
+    defect_fraction: float = 0.0,
+    n_seeds: int = 5,
+    impurity_c: float = 0.0,
+    output_prefix: str = "cet_run",
+):
+    """KMC microstructure evolution with natural defect injection (same contract as the
+    reference).  ``defect_fraction`` is the per-event probability that the just-updated voxel
+    becomes a defect."""
+    import cetkmc
+
+    np.random.seed(RANDOM_SEED)
+    random.seed(RANDOM_SEED)
+
+    output_dir = f"outputs/{output_prefix}"
+    os.makedirs(output_dir, exist_ok=True)
+
+    state, theta, phi, T, atom_type = initialize_lattice(
+        lattice_size=L, n_seeds=n_seeds, T_sub=temp, impurity_c=impurity_c)
+    defects_mask, defect_density = introduce_defects(state, atom_type, T, apply_to_state=False)
+
+    G = (T_MELT - T_SUB) / (L * VOXEL_SIZE)
+    R = NU_DEP * 2.74e-10 / VOXEL_SIZE
+    R_phys = NU_DEP * ATOMIC_SPACING_W
+    G_over_R_phys = G / R_phys
+
+    engine = cetkmc.Engine(L, impurity_c=impurity_c)
+    engine.upload(state, theta, phi, T, defects_mask)
+
+    total_time = 0.0
+    metrics_data = []
+    cet_detected = False
+    step = -1
+    next_step = 0
+    while next_step < n_steps:
+        # next step after which the host has work: metrics (and, on multiples of
+        # METRIC_UPDATE_STEP, the defect-mask refresh) -- kmc_simulation.py:335-341
+        stop = next_step if next_step % METRIC_UPDATE_STEP == 0 else \
+            min((next_step // METRIC_UPDATE_STEP + 1) * METRIC_UPDATE_STEP, n_steps - 1)
+        stop = min(stop, n_steps - 1)
+        done, terminated, last_total, dts = _advance_to(engine, next_step, stop, L, defect_fraction)
+        for dt in dts:
+            total_time += dt
+        if terminated:
+            step = next_step + done
+            print(f"Terminating at step {step}: no valid events (rate={last_total:.2e})")
+            break
+        step = stop
+        next_step = stop + 1
+
+        fields = engine.download()
+        state, theta, phi, T = fields["state"], fields["theta"], fields["phi"], fields["T"]
+        atom_type = state.copy()
+        if step % METRIC_UPDATE_STEP == 0:
+            defects_mask, defect_density = introduce_defects(state, atom_type, T, apply_to_state=False)
+            engine.set_defects(defects_mask)
+
+        m = compute_metrics(state, theta, phi, defects=defects_mask, voxel_size=VOXEL_SIZE)
+        defect_voxels = int(np.sum(atom_type == DEFECT_ID))
+        m["Defect_voxel_count"] = defect_voxels
+        m["DefectDensity"] = float(defect_voxels / atom_type.size)
+        if (not cet_detected) and detect_CET_transition(m):
+            cet_detected = True
+            print(f"CET detected at step {step} (G/R={G / R:.2e})")
+        row = {
+            "Step": step,
+            "Time": total_time,
+            "AspectRatio": m["AspectRatio"],
+            "EquiaxedFraction": m["EquiaxedFraction"],
+            "NucleationDensity": m["NucleationDensity"],
+            "DefectDensity": m["DefectDensity"],
+            "AvgGrainSize": m["AvgGrainSize"],
+            "GrainCount": m["GrainCount"],
+            "W_Count": int((state == 1).sum()),
+            "Re_Count": int((state == 2).sum()),
+            "C_Count": int((state == 3).sum()),
+            "NucleationCount": engine.nucleation_count(),
+            "G_over_R": (G / R) if R > 0 else np.inf,
+            "G_phys": G,
+            "R_phys": R_phys,
+            "G_over_R_phys": G_over_R_phys,
+            "CET_Class": compute_CET(state, theta, phi, voxel_size=VOXEL_SIZE),
+            "CET_Detected": cet_detected,
+        }
+        metrics_data.append(row)
+        print(
+            f"Step {step}: AR={row['AspectRatio']:.2f}, "
+            f"EqFrac={row['EquiaxedFraction']:.2f}, "
+            f"NucDens={row['NucleationDensity']:.3e}, "
+            f"DefectDens={row['DefectDensity']:.3e}, "
+            f"CET={row['CET_Class']}, "
+            f"Detected={row['CET_Detected']}, "
+            f"Time={row['Time']:.2e}s"
+        )
+
+    if metrics_data:
+        df = pd.DataFrame(metrics_data)
+        output_path = os.path.join(output_dir, "metrics.csv")
+        df.to_csv(output_path, index=False)
+        # plot_cet.py globs outputs/impurity_c_*/metrics_*.csv (plot_cet.py:26): also emit that name
+        tag = output_prefix.split("_")[-1]
+        df.to_csv(os.path.join(output_dir, f"metrics_{tag}.csv"), index=False)
+        print(f"Metrics saved to {output_path}")
+
+    fields = engine.download()
+    state, theta, phi = fields["state"], fields["theta"], fields["phi"]
+    atom_type = state.copy()
+    engine.close()
+    print(f"Completed {step + 1} steps in {total_time:.2e} s")
+    return state, atom_type, total_time, theta, phi

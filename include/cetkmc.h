@@ -1,0 +1,189 @@
+/*
+ * cetkmc.h -- C ABI of the MI355X-native rejection-free KMC stepping engine
+ *             (libcetkmc_hip.so; hand-written HIP kernels for gfx950).
+ *
+ * The reference (codebits1001/CET-driven-simulation-for-3D-printing-AM-KMC-Approach)
+ * is pure Python and has no FFI layer: its boundary for this path is the plain Python
+ * call surface of kmc_simulation.run_kmc / kmc_event_rates.get_event_rates /
+ * thermal_solver.update_temperature*.  Each entry point below names the reference
+ * code it replaces (file:line relative to the reference root).  The Python modules of
+ * the same names in this repository bind these symbols with ctypes.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; cetkmc_last_error()
+ *     returns a thread-local message.  Nothing throws across the boundary.
+ *   - the caller owns all host buffers; the library owns all device memory behind the
+ *     opaque handle.  A handle is not thread-safe; use one handle per host thread.
+ *   - host arrays are C-contiguous (L,L,L), axis 0 (i) slowest -- the reference layout.
+ *   - there is NO CPU fallback: without a usable gfx950 device cetkmc_create fails.
+ */
+#ifndef CETKMC_H
+#define CETKMC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CETKMC_ABI_VERSION 1
+
+/* Model constants (defaults = reference constants.py:34-148, thermal_solver.py:6-9).
+ * Passed by the host so that derived values carry the host's IEEE rounding. */
+typedef struct cetkmc_params {
+    double nu;             /* constants.py:70  NU            */
+    double nu_dep;         /* constants.py:71  NU_DEP        */
+    double E_b[3];         /* constants.py:74,80,84  W,Re,C  */
+    double E_diff[3];      /* constants.py:75,81,85          */
+    double kT;             /* constants.py:63  K_T           */
+    double T_melt;         /* constants.py:64                */
+    double I0;             /* constants.py:129               */
+    double delta_T_c;      /* constants.py:123               */
+    double K_nuc;          /* constants.py:130               */
+    double beta_imp_nuc;   /* constants.py:131               */
+    double max_imp_frac;   /* constants.py:90                */
+    double rate_threshold; /* constants.py:145               */
+    double anisotropy;     /* constants.py:102               */
+    double impurity_re;    /* constants.py:82                */
+    double impurity_c;     /* run_kmc / get_event_rates argument */
+    double alpha;          /* thermal_solver.py:9   K/(RHO*CP)   */
+    double inv_dx2;        /* thermal_solver.py:79,114  1/dx^2   */
+    double T_clip_lo;      /* thermal_solver.py:105,117  T_SUB   */
+    double T_clip_hi;      /* thermal_solver.py:105,117  1.1*T_MELT */
+    double T_nan;          /* kmc_simulation.py:249  nan_to_num(nan=T_SUB) */
+    double rho_cp;         /* thermal_solver.py:102  RHO*CP      */
+    double latent_coef;    /* thermal_solver.py:102  200e3/CP    */
+} cetkmc_params;
+
+/* One KMC event (an element of the list get_event_rates returns,
+ * kmc_event_rates.py:72,109,132,158).  64 bytes. */
+typedef struct cetkmc_event {
+    int32_t type;       /* 0 'dep', 1 'diff', 2 'nuc', 3 'att'; -1 = none            */
+    int32_t pos[3];     /* (i,j,k) of the event site                                   */
+    int32_t target[3];  /* diff: destination, att: source neighbour, else (-1,-1,-1)   */
+    int32_t atom;       /* species the event writes (dep: 0 until the species is drawn)*/
+    double  rate;       /* [1/s]                                                       */
+    int64_t dep_rank;   /* dep: index among the deposition candidates in row-major
+                           (j,k) order (selects the reference's per-candidate species
+                           draw, kmc_event_rates.py:65); else -1                       */
+    double  theta;      /* orientation written to the updated site (set by apply)     */
+    double  phi;
+} cetkmc_event;
+
+enum { CETKMC_DEP = 0, CETKMC_DIFF = 1, CETKMC_NUC = 2, CETKMC_ATT = 3 };
+
+/* Result of one full-lattice rate sweep (kmc_simulation.py:253-259). */
+typedef struct cetkmc_sweep_info {
+    double  total;      /* canonical-tree sum of all event rates           */
+    int64_t n_events;   /* len(events)                                                 */
+    int64_t n_dep;      /* number of deposition candidates (= RNG draws of the sweep)  */
+} cetkmc_sweep_info;
+
+/* Arguments of the batched stepping loop (kmc_simulation.py:246-332, n iterations).
+ * All pointers are HOST pointers; arrays are copied to the device once per call. */
+typedef struct cetkmc_run_args {
+    int64_t step0;            /* global index of the first step (thermal cadence step%20) */
+    int64_t n_steps;
+    double  defect_fraction;  /* kmc_simulation.py:323                                  */
+    const double* u_pick;     /* [n] random.random() for r            (:265)            */
+    const double* u_defect;   /* [n] random.random() defect draws (:323) or NULL if defect_fraction==0 */
+    const double* u_np;       /* NumPy global stream, consumed in order                 */
+    int64_t np_cap;           /* number of doubles in u_np                              */
+    int32_t rng_mode;         /* 0: reference stream (n_dep species draws per step + 2 orientation
+                                    draws per dep/nuc event);
+                                 1: counter-based species draw, stream holds only the orientation draws */
+    uint64_t seed;            /* rng_mode 1 key                                         */
+    int32_t thermal_mode;     /* 0 none, 1 update_temperature_cet every 20 steps (:248-250),
+                                 2 update_temperature (laser) every 20 steps             */
+    double  thermal_dt;       /* dt of the thermal update (run_kmc uses 1e-6)           */
+    const double* q_planes;   /* thermal_mode 2: [n_q][L*L] source planes, consumed in order */
+    int64_t n_q;
+    int32_t use_latent;       /* thermal_mode 2: latent-heat term on/off                */
+    int32_t profile;          /* 1: time every rate-sweep launch with hipEvents         */
+} cetkmc_run_args;
+
+typedef struct cetkmc_run_result {
+    int64_t steps_done;
+    int32_t status;           /* 0 ok, 1 terminated (no valid events, :260-262), 2 u_np exhausted */
+    int64_t np_used;          /* doubles of u_np consumed                               */
+    int64_t q_used;
+    int64_t nucleation_count; /* running total on the handle (:310)                     */
+    double  sweep_ms_total;   /* profile: sum of rate-sweep kernel durations            */
+    int64_t sweep_launches;
+    double  wall_ms;          /* device time of the whole call (hipEvents on the stream) */
+} cetkmc_run_result;
+
+const char* cetkmc_last_error(void);
+int cetkmc_abi_version(void);
+int cetkmc_device_count(int* n);
+
+/* Lifetime.  n_slabs > 1 with all device_ids equal splits the lattice into axis-0 slabs
+ * inside one process on one GPU (decomposition check mode).  Multi-GPU runs use one
+ * process per GPU: cetkmc_create_rank + an RCCL unique id shared by the launcher. */
+int cetkmc_create(const cetkmc_params* p, int L, int n_slabs, const int* device_ids, void** handle);
+int cetkmc_get_unique_id(char out[128]);
+int cetkmc_create_rank(const cetkmc_params* p, int L, int rank, int nranks, int device_id,
+                       const char unique_id[128], void** handle);
+int cetkmc_destroy(void* handle);
+int cetkmc_set_params(void* handle, const cetkmc_params* p);
+int cetkmc_sync(void* handle);
+/* planes [*i0,*i1) owned by this handle (whole lattice unless created with create_rank) */
+int cetkmc_owned_planes(void* handle, int* i0, int* i1);
+
+/* Lattice transfer in the reference's dtypes (run_kmc's arrays, kmc_simulation.py:226-233).
+ * NULL pointers leave the field unchanged / are not written. */
+int cetkmc_upload(void* handle, const int64_t* state, const double* theta, const double* phi,
+                  const double* T, const int64_t* defects);
+int cetkmc_download(void* handle, int64_t* state, double* theta, double* phi, double* T,
+                    int64_t* defects);
+/* Narrow transfer of planes [i_begin,i_end) only (arrays shaped (i_end-i_begin, L, L)); the
+ * range must cover the owned planes plus the 2-plane halo (clipped to the lattice). */
+int cetkmc_upload_planes(void* handle, int i_begin, int i_end, const uint8_t* state,
+                         const double* theta, const double* phi, const double* T,
+                         const uint8_t* defects);
+int cetkmc_download_planes(void* handle, int i_begin, int i_end, uint8_t* state, double* theta,
+                           double* phi, double* T, uint8_t* defects);
+/* defects.track_defects result (defects.py:4-19), full lattice, 0/1 bytes */
+int cetkmc_set_defects(void* handle, const uint8_t* mask);
+/* latent-heat reference state (thermal_solver.py:98); NULL = snapshot the current state */
+int cetkmc_set_prev_state(void* handle, const int64_t* prev_state);
+
+/* thermal_solver.update_temperature_cet (thermal_solver.py:107-117); scrub_nan applies
+ * np.nan_to_num(T, nan=T_SUB) first (kmc_simulation.py:249). */
+int cetkmc_thermal_cet(void* handle, double dt, int scrub_nan);
+/* thermal_solver.update_temperature (thermal_solver.py:36-105).  q_top = (L,L) volumetric
+ * source of plane i=L-1, i.e. I_surface/VOXEL_SIZE built by the host as the reference does
+ * (:82-95); the latent term uses the state set by cetkmc_set_prev_state. */
+int cetkmc_thermal_laser(void* handle, double dt, const double* q_top, int use_latent, int scrub_nan);
+
+/* kmc_event_rates.get_event_rates as a reduction (kmc_event_rates.py:162-176 +
+ * kmc_simulation.py:259): evaluates every event rate, leaves row/block sums on the device. */
+int cetkmc_rate_sweep(void* handle, cetkmc_sweep_info* info);
+/* kmc_simulation.py:265-274: pick the event whose cumulative rate first reaches r
+ * (canonical-tree order).  Needs a preceding cetkmc_rate_sweep. */
+int cetkmc_select(void* handle, double r, cetkmc_event* out);
+/* kmc_simulation.py:276-327: apply one event; theta/phi are the two np.random.uniform draws
+ * (dep/nuc); make_defect is the outcome of the defect-injection draw (:323). */
+int cetkmc_apply(void* handle, const cetkmc_event* ev, double theta_new, double phi_new, int make_defect);
+/* kmc_event_rates.get_event_rates in list form (parity / small L).  *n receives len(events);
+ * at most cap are written, in the reference's order. */
+int cetkmc_enumerate_events(void* handle, cetkmc_event* buf, int64_t cap, int64_t* n);
+/* Row sums/counts of the last sweep, shape (L,3,L) = [i][category dep/diff/empty][j]. */
+int cetkmc_row_sums(void* handle, double* rowsum, int32_t* rowcnt);
+
+/* kmc_simulation.py:246-332 for n steps without host round trips. totals/events/n_events
+ * (each [n_steps], may be NULL) receive the per-step total rate, chosen event and len(events). */
+int cetkmc_run_steps(void* handle, const cetkmc_run_args* args, cetkmc_run_result* res,
+                     double* totals, cetkmc_event* events, int64_t* n_events);
+
+int64_t cetkmc_nucleation_count(void* handle);
+int cetkmc_reset_counters(void* handle);
+
+/* Measurement helpers (bench.py): n back-to-back rate sweeps timed with hipEvents on the
+ * engine's stream; returns total milliseconds. */
+int cetkmc_time_sweeps(void* handle, int n, double* ms_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CETKMC_H */

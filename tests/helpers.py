@@ -140,3 +140,47 @@ def replay_run_kmc(z, make_backend, check_every_step=True, rate_rtol=1e-12):
     assert np.array_equal(np.array([random.random() for _ in range(4)]), z["py_next"])
     assert np.array_equal(np.random.random(4), z["np_next"])
     return be
+
+
+class GpuBackend:
+    """Backend protocol over cetkmc.Engine (single-step C-ABI entry points)."""
+
+    def __init__(self, state, theta, phi, T, defects, impurity_c, n_slabs=1):
+        import cetkmc
+        self.e = cetkmc.Engine(int(state.shape[0]), impurity_c=impurity_c, n_slabs=n_slabs)
+        self.e.upload(state, theta, phi, T, defects)
+
+    def thermal_cet(self, dt):
+        self.e.thermal_cet(dt, scrub_nan=True)
+
+    def sweep(self):
+        return self.e.rate_sweep()
+
+    def select(self, r):
+        return self.e.select(r)
+
+    def apply(self, ev, theta_new, phi_new, make_defect):
+        self.e.apply(ev, theta_new, phi_new, make_defect)
+
+    def set_defects(self, mask):
+        self.e.set_defects(mask)
+
+    def fields(self):
+        d = self.e.download()
+        return d["state"], d["theta"], d["phi"], d["T"]
+
+
+def random_lattice(L, seed, fill=0.3, t_lo=2600.0, t_hi=3690.0, hot_frac=0.05):
+    """Synthetic lattice exercising all four event families (test-only generator)."""
+    rs = np.random.RandomState(seed)
+    state = np.zeros((L, L, L), dtype=np.int64)
+    occ = rs.random_sample((L, L, L)) < fill
+    species = rs.choice([1, 2, 3, 4], size=(L, L, L), p=[0.6, 0.15, 0.2, 0.05])
+    state[occ] = species[occ]
+    theta = np.where((state != 0) & (state != 4), rs.uniform(0, np.pi, (L, L, L)), 0.0)
+    phi = np.where((state != 0) & (state != 4), rs.uniform(0, 2 * np.pi, (L, L, L)), 0.0)
+    T = rs.uniform(t_lo, t_hi, (L, L, L))
+    hot = rs.random_sample((L, L, L)) < hot_frac
+    T[hot] = rs.uniform(3690.0, 4064.5, int(hot.sum()))
+    defects = ((state == 3) & (rs.random_sample((L, L, L)) < 0.3)).astype(np.int64)
+    return state, theta, phi, T, defects

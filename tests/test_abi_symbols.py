@@ -1,0 +1,60 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/cetkmc.h declares;
+compute calls fail loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import PKG, ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "cetkmc.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cetkmc_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_header_symbols():
+    from cetkmc import _lib
+    _lib.build_library()
+    lib = ctypes.CDLL(_lib.SO_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), n
+    assert set(names) == set(_lib.PROTOTYPES), set(names) ^ set(_lib.PROTOTYPES)
+    lib.cetkmc_abi_version.restype = ctypes.c_int
+    assert lib.cetkmc_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    from cetkmc import _lib
+    assert ctypes.sizeof(_lib.Event) == 64
+    assert ctypes.sizeof(_lib.Params) == 26 * 8
+    assert ctypes.sizeof(_lib.SweepInfo) == 24
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product refuses to compute (skipped on the GPU box)."""
+    import cetkmc
+    from cetkmc import _lib
+    lib = _lib.load()
+    n = ctypes.c_int(0)
+    rc = lib.cetkmc_device_count(ctypes.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback|no usable HIP device"):
+        cetkmc.Engine(8)
+    import numpy as np
+    import thermal_solver
+    with pytest.raises(RuntimeError):
+        thermal_solver.update_temperature_cet(np.full((4, 4, 4), 3000.0), None)
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("# oracle", ""), os.path.join(dirpath, f)

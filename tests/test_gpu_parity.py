@@ -1,0 +1,305 @@
+"""HIP engine (through the C ABI) vs the oracle and the reference fixtures.  All tests here
+need a real MI355X: run with `pytest -m gpu` on the GPU box.
+
+Bars: integer/index results (event set, order, targets, species, counts, lattice state)
+bit-exact; rates within 1e-6 relative (the tests assert a much tighter 1e-11; device libm
+(ocml) and NumPy/glibc differ by a few ulp); temperature fields bit-exact.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, GpuBackend, OracleBackend, load, random_lattice, relerr, replay_run_kmc
+
+pytestmark = pytest.mark.gpu
+
+RATE_RTOL = 1e-11
+EVENT_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "events_*.npz")))
+TRAJ = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "traj_*.npz")))
+
+
+def _engine(z_or_L, impurity_c=0.0, n_slabs=1):
+    import cetkmc
+    return cetkmc.Engine(int(z_or_L), impurity_c=impurity_c, n_slabs=n_slabs)
+
+
+@pytest.mark.parametrize("name", EVENT_CASES)
+def test_enumerate_vs_reference_fixture(name):
+    z = load(name)
+    L = int(z["L"])
+    e = _engine(L, float(z["impurity_c"]))
+    e.upload(z["state"], z["theta"], z["phi"], z["T"], z["defects"])
+    ev, n = e.enumerate_events()
+    assert n == len(z["rate"]) == len(ev)
+    assert np.array_equal(ev["type"], z["etype"])
+    assert np.array_equal(ev["pos"], z["pos"])
+    assert np.array_equal(ev["target"], z["target"])
+    nd = z["etype"] != 0
+    assert np.array_equal(ev["atom"][nd], z["atom"][nd])
+    dep = ~nd
+    assert np.array_equal(ev["dep_rank"][dep], np.arange(int(dep.sum())))
+    if n:
+        assert relerr(ev["rate"], z["rate"]).max() <= RATE_RTOL
+
+
+@pytest.mark.parametrize("name", EVENT_CASES)
+def test_sweep_and_select_vs_oracle(oracle_mod, name):
+    z = load(name)
+    L = int(z["L"])
+    c = float(z["impurity_c"])
+    e = _engine(L, c)
+    e.upload(z["state"], z["theta"], z["phi"], z["T"], z["defects"])
+    lat = oracle_mod.Lattice(z["state"], z["theta"], z["phi"], z["T"], z["defects"], impurity_c=c)
+    sw = lat.sweep()
+    total, n_events, n_dep = e.rate_sweep()
+    assert (n_events, n_dep) == (sw["n_events"], sw["n_dep"])
+    rs, rc = e.row_sums()
+    assert np.array_equal(rc, sw["rowcnt"])
+    assert relerr(rs, sw["rowsum"]).max() <= RATE_RTOL
+    if n_events == 0:
+        return
+    assert abs(total - sw["total"]) <= RATE_RTOL * abs(sw["total"])
+    rng = np.random.RandomState(7)
+    for u in list(rng.random_sample(60)) + [0.0, 1.0 - 2.0 ** -53]:
+        want = lat.select_tree(sw["blocksum"], sw["blockcnt"], sw["rowsum"], sw["rowcnt"], u * sw["total"])
+        got = e.select(u * total)
+        assert (got.type, tuple(got.pos), tuple(got.target), got.dep_rank) == \
+               (want.type, tuple(want.pos), tuple(want.target), want.dep_rank), u
+        assert abs(got.rate - want.rate) <= RATE_RTOL * abs(want.rate)
+
+
+@pytest.mark.parametrize("L,seed", [(20, 1), (33, 2), (64, 3), (100, 4), (130, 5)])
+def test_sweep_vs_oracle_larger(oracle_mod, L, seed):
+    state, theta, phi, T, defects = random_lattice(L, seed, fill=0.2 if L < 100 else 0.05)
+    e = _engine(L, 0.15)
+    e.upload(state, theta, phi, T, defects)
+    lat = oracle_mod.Lattice(state, theta, phi, T, defects, impurity_c=0.15)
+    sw = lat.sweep()
+    total, n_events, n_dep = e.rate_sweep()
+    rs, rc = e.row_sums()
+    assert np.array_equal(rc, sw["rowcnt"])
+    assert (n_events, n_dep) == (sw["n_events"], sw["n_dep"])
+    assert relerr(rs, sw["rowsum"]).max() <= RATE_RTOL
+    assert abs(total - sw["total"]) <= RATE_RTOL * abs(sw["total"])
+
+
+def test_thermal_cet_fixtures():
+    z = load("thermal")
+    for L in (1, 2, 3, 7, 16):
+        Tin = z[f"cet_rand_L{L}_in"]
+        zero = np.zeros((L, L, L), np.int64)
+        for dt, key in ((1e-6, "out"), (3e-7, "out_dt3e-7")):
+            e = _engine(L)
+            e.upload(zero, Tin * 0, Tin * 0, Tin, zero)
+            e.thermal_cet(dt, scrub_nan=False)
+            assert np.array_equal(e.download()["T"], z[f"cet_rand_L{L}_{key}"]), (L, dt)
+    seq = z["cet_ramp_L12_seq"]
+    e = _engine(12)
+    zero = np.zeros((12, 12, 12), np.int64)
+    e.upload(zero, seq[0] * 0, seq[0] * 0, seq[0], zero)
+    for n in range(1, len(seq)):
+        e.thermal_cet(1e-6, scrub_nan=True)
+        assert np.array_equal(e.download()["T"], seq[n]), n
+    Tn = z["cet_nan_L6_in"]
+    e = _engine(6)
+    zero = np.zeros((6, 6, 6), np.int64)
+    e.upload(zero, zero.astype(float), zero.astype(float), Tn, zero)
+    e.thermal_cet(1e-6, scrub_nan=True)
+    assert np.array_equal(e.download()["T"], z["cet_nan_L6_out"])
+
+
+@pytest.mark.parametrize("L", [8, 13, 16])
+def test_thermal_laser(oracle_mod, L):
+    z = load("thermal")
+    for tag in ("dt1e-06", "dt1e-09"):
+        key = f"laser_L{L}_{tag}"
+        dt, i0, j0, P, rb, ab = z[key + "_par"]
+        T, prev, cur = z[key + "_T"], z[key + "_prev"], z[key + "_cur"]
+        q = oracle_mod.laser_source_plane(L, (i0, j0), P, rb, ab)
+        lat = oracle_mod.Lattice(cur, T * 0, T * 0, T)
+        want = lat.thermal_laser(dt, q, prev_state=prev)
+        e = _engine(L)
+        e.upload(cur.astype(np.int64), T * 0, T * 0, T, np.zeros_like(cur, dtype=np.int64))
+        e.set_prev_state(prev.astype(np.int64))
+        e.thermal_laser(dt, q, use_latent=True, scrub_nan=False)
+        got = e.download()["T"]
+        assert np.array_equal(got, want)                     # same source plane -> bit-exact
+        assert np.allclose(got, z[key + "_out"], rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("name", TRAJ)
+def test_replay_reference_trajectory_stepwise(name):
+    """run_kmc re-enacted with rate_sweep/select/apply through the C ABI, checked per step
+    against the reference-generated fixture (state diffs, T snapshots, counts, totals)."""
+    z = load(name)
+    every = int(z["L"]) <= 16
+    replay_run_kmc(z, lambda *a: GpuBackend(*a), check_every_step=every, rate_rtol=RATE_RTOL)
+
+
+def _drive_batched(engine_like, z, rng_mode=0, seed=0, batch=64):
+    """Batched protocol driver shared by the oracle and the device (same host RNG handling)."""
+    import random
+
+    import defects as host_defects
+    import lattice_init as host_init
+
+    L, n_steps = int(z["L"]), int(z["n_steps"])
+    temp, df = float(z["temp"]), float(z["defect_fraction"])
+    n_seeds, c = int(z["n_seeds"]), float(z["impurity_c"])
+    np.random.seed(42)
+    random.seed(42)
+    state, theta, phi, T, atom = host_init.initialize_lattice(lattice_size=L, n_seeds=n_seeds, T_sub=temp, impurity_c=c)
+    mask, _ = host_defects.introduce_defects(state, atom, T, apply_to_state=False)
+    be = engine_like(state, theta, phi, T, mask, c)
+    step, total_time = 0, 0.0
+    log = []
+    while step < n_steps:
+        nxt_refresh = step + 1 if step % 200 == 0 else (step // 200 + 1) * 200 + 1
+        n = min(n_steps, nxt_refresh, step + batch) - step
+        per = 3 if df > 0 else 2
+        draws = np.array([random.random() for _ in range(per * n)]).reshape(n, per)
+        np_state = np.random.get_state()
+        u_np = np.random.random(n * (L * L + 2))
+        res = be.run_steps(step, n, df, draws[:, 0], draws[:, 1] if df > 0 else None, u_np, rng_mode=rng_mode,
+                           seed=seed, thermal_mode=1)
+        assert res["status"] == 0 and res["done"] == n, res
+        np.random.set_state(np_state)
+        np.random.random(res["np_used"])
+        for s in range(n):
+            total_time += max(-np.log(max(1e-12, draws[s, -1])) / res["totals"][s], 1e-12)
+        log.append(res)
+        step += n
+        if (step - 1) % 200 == 0:
+            st, Tnow = be.state_and_T()
+            m, _ = host_defects.introduce_defects(st, st, Tnow, apply_to_state=False)
+            be.set_defects(m)
+    return be, total_time, log
+
+
+class _GpuBatched:
+    def __init__(self, state, theta, phi, T, defects, c, n_slabs=1):
+        import cetkmc
+        self.e = cetkmc.Engine(int(state.shape[0]), impurity_c=c, n_slabs=n_slabs)
+        self.e.upload(state, theta, phi, T, defects)
+
+    def run_steps(self, *a, **k):
+        return self.e.run_steps(*a, **k)
+
+    def state_and_T(self):
+        d = self.e.download()
+        return d["state"], d["T"]
+
+    def set_defects(self, m):
+        self.e.set_defects(m)
+
+    def final(self):
+        d = self.e.download()
+        return d["state"], d["theta"], d["phi"], d["T"]
+
+
+class _OracleBatched:
+    def __init__(self, oracle_mod, state, theta, phi, T, defects, c):
+        self.lat = oracle_mod.Lattice(state, theta, phi, T, defects, impurity_c=c)
+
+    def run_steps(self, *a, **k):
+        return self.lat.run_steps(*a, **k)
+
+    def state_and_T(self):
+        return self.lat.state.astype(np.int64), self.lat.T
+
+    def set_defects(self, m):
+        self.lat.defects = np.ascontiguousarray(m, dtype=np.int8)
+
+    def final(self):
+        return self.lat.state, self.lat.theta, self.lat.phi, self.lat.T
+
+
+@pytest.mark.parametrize("name", ["traj_L8_n60", "traj_L12_n40", "traj_L16_n100", "traj_L10_n450", "traj_L7_n230_T3400"])
+@pytest.mark.parametrize("n_slabs", [1, 2])
+def test_batched_loop_reference_trajectory(name, n_slabs):
+    """cetkmc_run_steps (no host round trips) reproduces the reference run, incl. RNG positions."""
+    import random
+    z = load(name)
+    be, total_time, _ = _drive_batched(lambda *a: _GpuBatched(*a, n_slabs=n_slabs), z, rng_mode=0)
+    st, th, ph, _ = be.final()
+    assert np.array_equal(st, z["final_state"])
+    assert np.array_equal(th, z["final_theta"]) and np.array_equal(ph, z["final_phi"])
+    assert total_time == float(z["total_time"])
+    assert np.array_equal(np.random.random(4), z["np_next"])
+    assert np.array_equal(np.array([random.random() for _ in range(4)]), z["py_next"])
+
+
+@pytest.mark.parametrize("rng_mode", [0, 1])
+def test_batched_loop_vs_oracle_medium(oracle_mod, rng_mode):
+    """Larger lattice, 120 steps, both RNG modes: per-step chosen events, totals, counts and the
+    final lattice equal the oracle's batched loop."""
+    z = dict(L=24, n_steps=120, temp=2800.0, defect_fraction=0.02, n_seeds=30, impurity_c=0.25)
+    g, tg, lg = _drive_batched(lambda *a: _GpuBatched(*a), z, rng_mode=rng_mode, seed=99, batch=50)
+    o, to, lo = _drive_batched(lambda *a: _OracleBatched(oracle_mod, *a), z, rng_mode=rng_mode, seed=99, batch=50)
+    for rg, ro in zip(lg, lo):
+        for f in ("type", "pos", "target", "atom", "dep_rank"):
+            assert np.array_equal(rg["events"][f], ro["events"][f]), f
+        assert np.array_equal(rg["events"]["theta"][np.isin(rg["events"]["type"], (0, 2))] >= 0, np.ones(int(np.isin(rg["events"]["type"], (0, 2)).sum()), bool))
+        assert np.array_equal(rg["n_events"], ro["n_events"])
+        assert relerr(rg["totals"], ro["totals"]).max() <= RATE_RTOL
+        assert rg["np_used"] == ro["np_used"]
+    for a, b in zip(g.final(), o.final()):
+        assert np.array_equal(a, b)
+    assert tg == to
+
+
+@pytest.mark.parametrize("n_slabs", [2, 3, 5])
+def test_slab_decomposition_bit_identical(n_slabs):
+    """Axis-0 slabs (halo 2) give bit-identical totals, events and fields to the undivided lattice."""
+    L = 20
+    state, theta, phi, T, defects = random_lattice(L, 11, fill=0.25)
+    rs = np.random.RandomState(5)
+    n = 90
+    u_pick, u_def, u_np = rs.random_sample(n), rs.random_sample(n), rs.random_sample(n * (L * L + 2))
+    outs = []
+    for ns in (1, n_slabs):
+        e = _engine(L, 0.2, n_slabs=ns)
+        e.upload(state, theta, phi, T, defects)
+        res = e.run_steps(0, n, 0.05, u_pick, u_def, u_np, rng_mode=0, thermal_mode=1)
+        outs.append((res, e.download(defects=True)))
+    (r1, d1), (r2, d2) = outs
+    assert r1["done"] == r2["done"] == n
+    assert np.array_equal(r1["totals"], r2["totals"])            # bit-identical sums
+    assert r1["events"].tobytes() == r2["events"].tobytes()
+    for k in d1:
+        assert np.array_equal(d1[k], d2[k]), k
+
+
+def test_transfers_and_errors():
+    import cetkmc
+    L = 9
+    state, theta, phi, T, defects = random_lattice(L, 3)
+    e = _engine(L, 0.1, n_slabs=2)
+    e.upload(state, theta, phi, T, defects)
+    d = e.download(defects=True)
+    for k, want in (("state", state), ("theta", theta), ("phi", phi), ("T", T), ("defects", defects)):
+        assert np.array_equal(d[k], want), k
+    p = e.download_planes(2, 7, state=True, theta=True, T=True, defects=True)
+    assert np.array_equal(p["state"], state[2:7]) and np.array_equal(p["T"], T[2:7])
+    e2 = _engine(L, 0.1)
+    e2.upload_planes(0, L, state.astype(np.uint8), theta, phi, T, defects.astype(np.uint8))
+    assert e2.rate_sweep() == e.rate_sweep()
+    bad = state.copy()
+    bad[0, 0, 0] = 300
+    with pytest.raises(RuntimeError):
+        e.upload(bad, theta, phi, T, defects)
+    with pytest.raises(RuntimeError):
+        cetkmc.Engine(2000)
+    e3 = _engine(4)
+    with pytest.raises(RuntimeError):
+        e3.select(0.5)                     # no sweep yet
+    z = np.zeros((4, 4, 4))
+    occ = np.full((4, 4, 4), 4, dtype=np.int64)
+    e3.upload(occ, z, z, z + 3000.0, occ * 0)
+    assert e3.rate_sweep()[1] == 0         # defect-only lattice: no events
+    with pytest.raises(RuntimeError):
+        e3.select(0.0)
+    res = e3.run_steps(0, 5, 0.0, np.full(5, 0.5), None, np.zeros(64), thermal_mode=0)
+    assert res["status"] == 1 and res["done"] == 0     # kmc_simulation.py:260-262
