@@ -347,15 +347,20 @@ int download_impl(Handle* h, int i_begin, int i_end, I* state, double* theta, do
 }
 
 // ---- per-step launches (all asynchronous on h->stream) -----------------------------------
-int launch_sweep(Handle* h, bool batch)
+int launch_sweep(Handle* h, bool batch, hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr)
 {
     const int TR = SWEEP_TJ + 4;
     const size_t shmem = (size_t)((5 * TR * h->pitchS + 15) & ~15) + 225 * sizeof(double);
     const StepState* ss = batch ? h->d_ss : nullptr;
+    const int njt = (h->L + SWEEP_TJ - 1) / SWEEP_TJ;
+    if (ev_a) HIPCHK(hipEventRecord(ev_a, h->stream));
     for (size_t s = 0; s < h->slabs.size(); ++s) {
         SlabView v = view_of(h, (int)s);
-        const int njt = (h->L + SWEEP_TJ - 1) / SWEEP_TJ;
         hipLaunchKernelGGL(k_sweep, dim3(v.nloc * njt), dim3(256), shmem, h->stream, h->kp, v, h->d_ktab, ss);
+    }
+    if (ev_b) HIPCHK(hipEventRecord(ev_b, h->stream));
+    for (size_t s = 0; s < h->slabs.size(); ++s) {
+        SlabView v = view_of(h, (int)s);
         hipLaunchKernelGGL(k_plane_reduce, dim3(3 * v.nloc), dim3(64), 0, h->stream, v, h->d_blocks, ss);
     }
     HIPCHK(hipGetLastError());
@@ -808,9 +813,8 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
             if (a->thermal_mode == 1) CHK(launch_thermal(h, a->thermal_dt, 0, nullptr, 0, 1, true));
             else { CHK(launch_thermal(h, a->thermal_dt, 1, h->d_q + (size_t)q_idx * L2, a->use_latent, 1, true)); ++q_idx; }
         }
-        if (a->profile) HIPCHK(hipEventRecord(h->prof[2 * s], h->stream));
-        CHK(launch_sweep(h, true));
-        if (a->profile) HIPCHK(hipEventRecord(h->prof[2 * s + 1], h->stream));
+        if (a->profile) CHK(launch_sweep(h, true, h->prof[2 * s], h->prof[2 * s + 1]));
+        else CHK(launch_sweep(h, true));
         CHK(launch_select(h, cfg, 0.0, 0));
         hipLaunchKernelGGL(k_apply_batch, dim3(1), dim3(64), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
                            (int)h->slabs.size(), h->L, (const cetkmc_event*)h->d_events_all, h->G, h->d_ss, cfg,

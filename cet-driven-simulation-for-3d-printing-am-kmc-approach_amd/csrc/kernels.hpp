@@ -521,7 +521,7 @@ __global__ void k_enumerate(KParams P, SlabView S, const double* __restrict__ kt
                             cetkmc_event* out, int64_t cap)
 {
     __shared__ double ktab[225];
-    if (threadIdx.x < 225) ktab[threadIdx.x] = ktab_g[threadIdx.x];
+    for (int t = threadIdx.x; t < 225; t += blockDim.x) ktab[t] = ktab_g[t];
     __syncthreads();
     const int L = S.L;
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
