@@ -64,6 +64,7 @@ PROTOTYPES = {
     "cetkmc_destroy": (C.c_int, [C.c_void_p]),
     "cetkmc_set_params": (C.c_int, [C.c_void_p, _P(Params)]),
     "cetkmc_sync": (C.c_int, [C.c_void_p]),
+    "cetkmc_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "cetkmc_owned_planes": (C.c_int, [C.c_void_p, _P(C.c_int), _P(C.c_int)]),
     "cetkmc_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cetkmc_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

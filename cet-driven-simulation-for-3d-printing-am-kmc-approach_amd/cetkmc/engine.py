@@ -263,5 +263,8 @@ class Engine:
         self._ck(self.lib.cetkmc_time_sweeps(self.h, int(n), C.byref(ms)))
         return ms.value
 
+    def set_option(self, key, value):
+        self._ck(self.lib.cetkmc_set_option(self.h, key.encode(), int(value)))
+
     def sync(self):
         self._ck(self.lib.cetkmc_sync(self.h))

@@ -85,13 +85,13 @@ struct Slab {
     SlabView v{};
     uint8_t* prev = nullptr;
     double* Tbuf[2] = {nullptr, nullptr};
-    size_t nS = 0, nT = 0;   // bytes of a u8 array, doubles of an f64 array
+    size_t nS = 0, nT = 0, nC = 0;   // bytes of a u8 array, doubles of an f64 array, u16s of the class array
 };
 
 struct Handle {
     cetkmc_params p{};
     KParams kp{};
-    int L = 0, Pk = 1, PB = 1, RJ = 0, pitchS = 0, pitchT = 0;
+    int L = 0, Pk = 1, PB = 1, RJ = 0, pitchS = 0, pitchT = 0, pitchC = 0;
     int dev = 0;
     hipStream_t stream = nullptr;
     std::vector<Slab> slabs;
@@ -103,6 +103,7 @@ struct Handle {
     cetkmc_event* d_events_all = nullptr;
     StepState* d_ss = nullptr;
     double* d_ktab = nullptr;
+    KParams* d_kp = nullptr;
     void* d_scratch = nullptr;
     size_t scratch_bytes = 0;
     int* d_flag = nullptr;
@@ -116,6 +117,8 @@ struct Handle {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
     bool swept = false;
+    int sweep_variant = 2;
+    size_t shmem_march = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> prof;
 };
@@ -150,6 +153,7 @@ int upload_ktab(Handle* h)
     for (int a = 0; a < 15; ++a)
         for (int b = 0; b < 15; ++b) tab[a * 15 + b] = host_k_eff(h->p, a, b);
     HIPCHK(hipMemcpyAsync(h->d_ktab, tab, sizeof tab, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_kp, &h->kp, sizeof(KParams), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -192,6 +196,11 @@ int create_common(const cetkmc_params* p, int L, const std::vector<std::pair<int
     h->RJ = round_up(L, SWEEP_TJ) + 4;
     h->pitchS = round_up(KOFF + L + 4, 16);
     h->pitchT = round_up(L, 2);
+    h->pitchC = round_up(KOFFC + L + 8, 8);
+    h->shmem_march = (size_t)((5 * (SWEEP_TJ + 4) * h->pitchC * 2 + 15) & ~15) + (226 + MARCH_Q + SWEEP_TJ * 3 * MARCH_MAXCH) * sizeof(double)
+                     + MARCH_Q * sizeof(unsigned) + 4 * sizeof(int);
+    if (h->shmem_march > 160 * 1024) { delete h; return fail("L too large for the LDS ring"); }
+    HIPCHK(hipFuncSetAttribute((const void*)k_sweep_march, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->shmem_march));
     h->dev = dev; h->G = G; h->my_first = my_first;
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&h->ev0));
@@ -201,9 +210,12 @@ int create_common(const cetkmc_params* p, int L, const std::vector<std::pair<int
     for (auto& r : ranges) {
         Slab s;
         s.v.L = L; s.v.gi0 = r.first; s.v.nloc = r.second;
-        s.v.RJ = h->RJ; s.v.pitchS = h->pitchS; s.v.pitchT = h->pitchT; s.v.Pk = h->Pk;
+        s.v.RJ = h->RJ; s.v.pitchS = h->pitchS; s.v.pitchT = h->pitchT; s.v.Pk = h->Pk; s.v.pitchC = h->pitchC;
         s.nS = (size_t)(r.second + 4) * h->RJ * h->pitchS;
         s.nT = (size_t)(r.second + 4) * L * h->pitchT;
+        s.nC = (size_t)(r.second + 4) * h->RJ * h->pitchC;
+        HIPCHK(hipMalloc((void**)&s.v.cls, s.nC * sizeof(uint16_t)));
+        HIPCHK(hipMemsetAsync(s.v.cls, 0, s.nC * sizeof(uint16_t), h->stream));
         HIPCHK(hipMalloc((void**)&s.v.state, s.nS));
         HIPCHK(hipMalloc((void**)&s.v.defects, s.nS));
         HIPCHK(hipMalloc((void**)&s.prev, s.nS));
@@ -219,6 +231,7 @@ int create_common(const cetkmc_params* p, int L, const std::vector<std::pair<int
         HIPCHK(hipMalloc((void**)&s.v.phi, s.nT * sizeof(double)));
         HIPCHK(hipMemsetAsync(s.v.theta, 0, s.nT * sizeof(double), h->stream));
         HIPCHK(hipMemsetAsync(s.v.phi, 0, s.nT * sizeof(double), h->stream));
+        HIPCHK(hipMalloc((void**)&s.v.ovec, 3 * s.nT * sizeof(double)));
         HIPCHK(hipMalloc((void**)&s.v.rowsum, (size_t)r.second * 3 * L * sizeof(double)));
         HIPCHK(hipMalloc((void**)&s.v.rowcnt, (size_t)r.second * 3 * L * sizeof(int32_t)));
         HIPCHK(hipMemsetAsync(s.v.rowsum, 0, (size_t)r.second * 3 * L * sizeof(double), h->stream));
@@ -233,10 +246,14 @@ int create_common(const cetkmc_params* p, int L, const std::vector<std::pair<int
     HIPCHK(hipMalloc((void**)&h->d_ss, sizeof(StepState)));
     HIPCHK(hipMemsetAsync(h->d_ss, 0, sizeof(StepState), h->stream));
     HIPCHK(hipMalloc((void**)&h->d_ktab, 225 * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&h->d_kp, sizeof(KParams)));
     HIPCHK(hipMalloc((void**)&h->d_flag, sizeof(int)));
     HIPCHK(hipMalloc((void**)&h->d_qtop, (size_t)L * L * sizeof(double)));
     CHK(upload_ktab(h));
     CHK(push_views(h));
+    for (auto& s : h->slabs) hipLaunchKernelGGL(k_orient, dim3(1024), dim3(256), 0, h->stream, s.v);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
     *out = h;
     return 0;
 }
@@ -271,7 +288,7 @@ int d2h_f64(Handle* h, const Slab& s, const double* srcd, double* dst, int i_beg
 }
 
 template <class SRC>
-int h2d_u8(Handle* h, const Slab& s, uint8_t* dst, const SRC* src, int i_begin, int a, int b, bool check)
+int h2d_u8(Handle* h, const Slab& s, uint8_t* dst, const SRC* src, int i_begin, int a, int b, bool check, int with_cls = 0)
 {
     const int L = h->L;
     const size_t n = (size_t)(b - a) * L * L;
@@ -281,14 +298,14 @@ int h2d_u8(Handle* h, const Slab& s, uint8_t* dst, const SRC* src, int i_begin, 
     if (check) {
         if constexpr (sizeof(SRC) == 8) {
             HIPCHK(hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
-            hipLaunchKernelGGL(k_check_range, dim3(grid), dim3(256), 0, h->stream, (const int64_t*)h->d_scratch, (int64_t)n, 0, 127, h->d_flag);
+            hipLaunchKernelGGL(k_check_range, dim3(grid), dim3(256), 0, h->stream, (const int64_t*)h->d_scratch, (int64_t)n, 0, 4, h->d_flag);
             int bad = 0;
             HIPCHK(hipMemcpyAsync(&bad, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
-            if (bad) return fail("state/defects values must lie in 0..127");
+            if (bad) return fail("state/defects values must lie in 0..4 (constants.STATES)");
         }
     }
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pack_u8<SRC>), dim3(grid), dim3(256), 0, h->stream, s.v, dst, (const SRC*)h->d_scratch, a, b - a);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pack_u8<SRC>), dim3(grid), dim3(256), 0, h->stream, s.v, dst, (const SRC*)h->d_scratch, a, b - a, with_cls);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));   // scratch is reused by the next field
     return 0;
@@ -317,14 +334,16 @@ int upload_impl(Handle* h, int i_begin, int i_end, const I* state, const double*
         ext_range(h, s, &a, &b);
         if (a < i_begin || b > i_end) return fail("upload range does not cover the slab's planes + halo");
         if (state) {
-            CHK(h2d_u8<I>(h, s, s.v.state, state, i_begin, a, b, true));
+            CHK(h2d_u8<I>(h, s, s.v.state, state, i_begin, a, b, true, 1));
             HIPCHK(hipMemcpyAsync(s.prev, s.v.state, s.nS, hipMemcpyDeviceToDevice, h->stream));
         }
         if (defects) CHK(h2d_u8<I>(h, s, s.v.defects, defects, i_begin, a, b, true));
         if (theta) CHK(h2d_f64(h, s, s.v.theta, theta, i_begin, a, b));
         if (phi) CHK(h2d_f64(h, s, s.v.phi, phi, i_begin, a, b));
         if (T) CHK(h2d_f64(h, s, s.Tbuf[h->cur], T, i_begin, a, b));
+        if (theta || phi) hipLaunchKernelGGL(k_orient, dim3(1024), dim3(256), 0, h->stream, s.v);
     }
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     h->swept = false;
     return 0;
@@ -350,13 +369,27 @@ int download_impl(Handle* h, int i_begin, int i_end, I* state, double* theta, do
 int launch_sweep(Handle* h, bool batch, hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr)
 {
     const int TR = SWEEP_TJ + 4;
-    const size_t shmem = (size_t)((5 * TR * h->pitchS + 15) & ~15) + 225 * sizeof(double);
+    const size_t tile = (size_t)((5 * TR * h->pitchS + 15) & ~15);
+    const size_t shmem0 = tile + 225 * sizeof(double);
+    const size_t shmem1 = tile + 226 * sizeof(double) + (size_t)SWEEP_Q * (sizeof(double) + sizeof(unsigned)) + 4 * sizeof(int);
     const StepState* ss = batch ? h->d_ss : nullptr;
     const int njt = (h->L + SWEEP_TJ - 1) / SWEEP_TJ;
     if (ev_a) HIPCHK(hipEventRecord(ev_a, h->stream));
     for (size_t s = 0; s < h->slabs.size(); ++s) {
         SlabView v = view_of(h, (int)s);
-        hipLaunchKernelGGL(k_sweep, dim3(v.nloc * njt), dim3(256), shmem, h->stream, h->kp, v, h->d_ktab, ss);
+        if (h->sweep_variant == 2) {
+            const int nib = (v.nloc + MARCH_NI - 1) / MARCH_NI;
+            MarchArgs ma{};
+            ma.T_melt = h->kp.T_melt; ma.delta_T_c = h->kp.delta_T_c; ma.kT = h->kp.kT; ma.I0 = h->kp.I0;
+            ma.rate_threshold = h->kp.rate_threshold; ma.nu_dep = h->kp.nu_dep;
+            ma.L = v.L; ma.gi0 = v.gi0; ma.nloc = v.nloc; ma.RJ = v.RJ; ma.pitchC = v.pitchC; ma.pitchT = v.pitchT; ma.Pk = v.Pk;
+            ma.cls = v.cls; ma.T = v.T; ma.rowsum = v.rowsum; ma.rowcnt = v.rowcnt;
+            hipLaunchKernelGGL(k_sweep_march, dim3(nib * njt), dim3(256), h->shmem_march, h->stream, ma,
+                               (const KParams*)h->d_kp, (const SlabView*)(h->d_views[h->cur] + s), h->d_ktab, ss);
+        } else if (h->sweep_variant == 0)
+            hipLaunchKernelGGL(k_sweep_simple, dim3(v.nloc * njt), dim3(256), shmem0, h->stream, h->kp, v, h->d_ktab, ss);
+        else
+            hipLaunchKernelGGL(k_sweep, dim3(v.nloc * njt), dim3(256), shmem1, h->stream, h->kp, v, h->d_ktab, ss);
     }
     if (ev_b) HIPCHK(hipEventRecord(ev_b, h->stream));
     for (size_t s = 0; s < h->slabs.size(); ++s) {
@@ -456,11 +489,11 @@ void destroy_impl(Handle* h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     for (auto& s : h->slabs) {
-        (void)hipFree(s.v.state); (void)hipFree(s.v.defects); (void)hipFree(s.prev);
-        (void)hipFree(s.Tbuf[0]); (void)hipFree(s.Tbuf[1]); (void)hipFree(s.v.theta); (void)hipFree(s.v.phi);
+        (void)hipFree(s.v.state); (void)hipFree(s.v.defects); (void)hipFree(s.prev); (void)hipFree(s.v.cls);
+        (void)hipFree(s.Tbuf[0]); (void)hipFree(s.Tbuf[1]); (void)hipFree(s.v.theta); (void)hipFree(s.v.phi); (void)hipFree(s.v.ovec);
         (void)hipFree(s.v.rowsum); (void)hipFree(s.v.rowcnt);
     }
-    void* ptrs[] = {h->d_views[0], h->d_views[1], h->d_blocks, h->d_events_all, h->d_ss, h->d_ktab, h->d_scratch,
+    void* ptrs[] = {h->d_views[0], h->d_views[1], h->d_blocks, h->d_events_all, h->d_ss, h->d_ktab, h->d_kp, h->d_scratch,
                     h->d_flag, h->d_qtop, h->d_u_pick, h->d_u_defect, h->d_u_np, h->d_q, h->d_log_total,
                     h->d_log_event, h->d_log_nev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -549,6 +582,18 @@ int cetkmc_set_params(void* handle, const cetkmc_params* p)
     h->p = *p; h->kp = make_kparams(*p);
     h->swept = false;
     return upload_ktab(h);
+}
+
+int cetkmc_set_option(void* handle, const char* key, int64_t value)
+{
+    Handle* h = (Handle*)handle;
+    if (!h || !key) return fail("null argument");
+    if (!strcmp(key, "sweep_variant")) {
+        if (value < 0 || value > 2) return fail("sweep_variant must be 0 (simple), 1 (queued) or 2 (marching, default)");
+        h->sweep_variant = (int)value;
+        return 0;
+    }
+    return fail(std::string("unknown option ") + key);
 }
 
 int cetkmc_sync(void* handle)

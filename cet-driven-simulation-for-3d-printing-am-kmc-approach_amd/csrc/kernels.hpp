@@ -73,13 +73,14 @@ __device__ __forceinline__ double stack_push(double (&stk)[LV], double t, int m)
 }
 
 // ----------------------------------------------------------------------------------------
-// k_sweep: one block = one owned plane x SWEEP_TJ rows.  The 14-neighbour state stencil is
+// k_sweep_simple (variant 0, straightforward reference form kept for A/B and cross-checks):
+// one block = one owned plane x SWEEP_TJ rows.  The 14-neighbour state stencil is
 // staged in LDS (5 planes x (TJ+4) rows of the padded u8 state array, 16-B loads); T is
 // streamed once, 16 B per lane; theta/phi/defects/T-neighbours are gathered only at
 // interface voxels.  Each wave reduces its rows with xor-butterflies (balanced tree over k).
 // ----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_sweep(KParams P, SlabView S, const double* __restrict__ ktab_g,
-                                               const StepState* __restrict__ ss)
+__global__ __launch_bounds__(256) void k_sweep_simple(KParams P, SlabView S, const double* __restrict__ ktab_g,
+                                                      const StepState* __restrict__ ss)
 {
     if (ss && ss->status) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256) void k_sweep(KParams P, SlabView S, const doub
                     const int st = (k < S.L) ? own_row[k] : OOB;
                     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
                     auto nb = [&](int mm) -> int {
-                        return smem[(int64_t)((nbi(mm) + 2) * TR + (r + 2 + nbj(mm))) * pitchS + KOFF + k + nbk(mm)];
+                        return smem[(int64_t)((nbi_rt(mm) + 2) * TR + (r + 2 + nbj_rt(mm))) * pitchS + KOFF + k + nbk_rt(mm)];
                     };
                     auto emit = [&](int cat, int, double rate, int, int) {
                         if (cat == CAT_DEP) { a0 += rate; cpack += 1; }
@@ -154,6 +155,454 @@ __global__ __launch_bounds__(256) void k_sweep(KParams P, SlabView S, const doub
             S.rowsum[o] = row0; S.rowsum[o + S.L] = row1; S.rowsum[o + 2 * S.L] = row2;
             S.rowcnt[o] = c0; S.rowcnt[o + S.L] = c1; S.rowcnt[o + 2 * S.L] = c2;
         }
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// k_sweep (variant 1): same tiling, but the rare transcendental-heavy events (attachment,
+// diffusion: only at occupied/empty interfaces) are NOT evaluated by the lane that owns the
+// voxel.  Phase A evaluates the cheap per-voxel part (deposition, nucleation, neighbour census)
+// for 2 voxels per lane; every interface event becomes a 4-byte work item in an LDS queue;
+// phase B spreads the items over consecutive lanes (full waves instead of 1-2 busy lanes);
+// phase C lets each owner add its items' rates in slot order, so the voxel sums -- and hence
+// the canonical tree -- are bit-identical to the simple form.
+// ----------------------------------------------------------------------------------------
+constexpr int SWEEP_Q = 2048;   // item queue capacity per round
+
+__device__ __forceinline__ double sweep_item_rate(const KParams& P, const SlabView& S, const unsigned char* smem,
+                                                  int li, int j0, unsigned desc)
+{
+    constexpr int TR = SWEEP_TJ + 4;
+    const int r = desc & 7, k = (desc >> 3) & 1023, m = (desc >> 13) & 15, n_bonds = (desc >> 17) & 15;
+    const int j = j0 + r;
+    const int di = nbi_rt(m), dj = nbj_rt(m), dk = nbk_rt(m);
+    const int st = smem[(int64_t)(2 * TR + r + 2) * S.pitchS + KOFF + k];
+    const double Tc = pymax(S.T[S.tidx(li, j, k)], 1.0);
+    double rate;
+    if (st == 0) {
+        const int sn = smem[(int64_t)((di + 2) * TR + (r + 2 + dj)) * S.pitchS + KOFF + k + dk];
+        rate = att_rate(P, S, li, j, k, di, dj, dk, sn, Tc);
+    } else {
+        rate = diff_rate(P, S, li, j, k, di, dj, dk, st, n_bonds, Tc);
+    }
+    return (rate > P.rate_threshold && finite_d(rate)) ? rate : -1.0;
+}
+
+__global__ __launch_bounds__(256) void k_sweep(KParams P, SlabView S, const double* __restrict__ ktab_g,
+                                               const StepState* __restrict__ ss)
+{
+    if (ss && ss->status) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TJ = SWEEP_TJ, TR = TJ + 4;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int njt = (S.L + TJ - 1) / TJ;
+    const int nblk = S.nloc * njt;
+    int b = blockIdx.x;
+    if ((nblk & 7) == 0) b = (b & 7) * (nblk >> 3) + (b >> 3);   // contiguous plane ranges per XCD
+    const int lp = b / njt, jt = b - lp * njt;
+    const int j0 = jt * TJ, li = lp + 2, i = S.gi0 + lp;
+    const int pitchS = S.pitchS;
+    const int tile_bytes = (5 * TR * pitchS + 15) & ~15;
+    double* ktab = reinterpret_cast<double*>(smem + tile_bytes);
+    double* qres = ktab + 226;                                       // [SWEEP_Q]
+    unsigned* qdesc = reinterpret_cast<unsigned*>(qres + SWEEP_Q);   // [SWEEP_Q]
+    int* wave_tot = reinterpret_cast<int*>(qdesc + SWEEP_Q);         // [4]
+
+    {
+        const int cpr = pitchS >> 4;
+        const int nchunk = 5 * TR * cpr;
+        for (int idx = tid; idx < nchunk; idx += 256) {
+            int row = idx / cpr, ch = idx - row * cpr;
+            int p = row / TR, rr = row - p * TR;
+            const uint4* src = reinterpret_cast<const uint4*>(S.state + ((int64_t)(li - 2 + p) * S.RJ + (j0 + rr)) * pitchS) + ch;
+            reinterpret_cast<uint4*>(smem + (int64_t)row * pitchS)[ch] = *src;
+        }
+        if (tid < 225) ktab[tid] = ktab_g[tid];
+    }
+    __syncthreads();
+
+    const bool top = (i == S.L - 1);
+    const int nch = S.Pk > 128 ? (S.Pk >> 7) : 1;
+    double stk0[2][4], stk1[2][4], stk2[2][4];
+    double row0[2] = {0.0, 0.0}, row1[2] = {0.0, 0.0}, row2[2] = {0.0, 0.0};
+    int c0[2] = {0, 0}, c1[2] = {0, 0}, c2[2] = {0, 0};
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int r = w + 4 * rr;
+        const int j = j0 + r;
+        const unsigned char* own_row = smem + (int64_t)(2 * TR + r + 2) * pitchS + KOFF;
+        for (int m = 0; m < nch; ++m) {
+            const int k0 = (m << 7) + 2 * lane;
+            // ---- phase A: cheap part of both voxels ------------------------------------------
+            double mainv[2] = {0.0, 0.0}, depv[2] = {0.0, 0.0};
+            unsigned info[2] = {0u, 0u};   // [0:13] item mask  [14:17] n_bonds  [18] main valid  [19] dep valid  [20:21] 1 diff / 2 empty
+            if (j < S.L && k0 < S.L) {
+                const double2 Tv = *reinterpret_cast<const double2*>(S.T + S.tidx(li, j, k0));
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int k = k0 + h;
+                    const int st = (k < S.L) ? own_row[k] : OOB;
+                    if (st < 128 && st != 4) {
+                        int n_nb = 0, n_imp = 0, n_occ = 0;
+                        unsigned m_src = 0, m_empty = 0;
+#pragma unroll
+                        for (int mm = 0; mm < 14; ++mm) {
+                            const int sm = smem[(int64_t)((nbi_rt(mm) + 2) * TR + (r + 2 + nbj_rt(mm))) * pitchS + KOFF + k + nbk_rt(mm)];
+                            n_nb += (sm != OOB);
+                            n_imp += (sm == 2 || sm == 3);
+                            n_occ += (sm != 0 && sm != OOB);
+                            if (sm >= 1 && sm <= 3) m_src |= 1u << mm;
+                            if (sm == 0) m_empty |= 1u << mm;
+                        }
+                        const double Tc = pymax(h ? Tv.y : Tv.x, 1.0);
+                        if (st == 0) {
+                            unsigned inf = m_src | (2u << 20);
+                            if (top) {
+                                const double rate = dep_rate(P, Tc);
+                                if (finite_d(rate)) { depv[h] = rate; inf |= 1u << 19; }
+                            }
+                            const double dT = P.T_melt - Tc;
+                            if (dT > P.delta_T_c) {
+                                const double rate = nuc_rate(P, ktab[n_nb * 15 + n_imp], dT, P.kT * Tc);
+                                if (rate > P.rate_threshold && finite_d(rate)) { mainv[h] = rate; inf |= 1u << 18; }
+                            }
+                            info[h] = inf;
+                        } else {
+                            info[h] = m_empty | ((unsigned)n_occ << 14) | (1u << 20);
+                        }
+                    }
+                }
+            }
+            // ---- phase B: interface events through the block-wide item queue ----------------------
+            const int n0 = __builtin_popcount(info[0] & 0x3FFF), n1 = __builtin_popcount(info[1] & 0x3FFF);
+            int cnt[2] = {(int)((info[0] >> 18) & 1), (int)((info[1] >> 18) & 1)};
+            if (__syncthreads_or(n0 + n1)) {
+                int incl = n0 + n1;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+                if (lane == 63) wave_tot[w] = incl;
+                __syncthreads();
+                int base = incl - (n0 + n1), total = 0;
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) { const int t = wave_tot[ww]; if (ww < w) base += t; total += t; }
+                const int nrounds = (total + SWEEP_Q - 1) / SWEEP_Q;
+                for (int rho = 0; rho < nrounds; ++rho) {
+                    if (rho) __syncthreads();
+                    int g = base;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        unsigned mk = info[h] & 0x3FFF;
+                        while (mk) {
+                            const int mm = __builtin_ctz(mk);
+                            mk &= mk - 1;
+                            if (g / SWEEP_Q == rho)
+                                qdesc[g % SWEEP_Q] = (unsigned)r | ((unsigned)(k0 + h) << 3) | ((unsigned)mm << 13) | (((info[h] >> 14) & 15u) << 17);
+                            ++g;
+                        }
+                    }
+                    __syncthreads();
+                    const int nq = min(SWEEP_Q, total - rho * SWEEP_Q);
+                    for (int q = tid; q < nq; q += 256) qres[q] = sweep_item_rate(P, S, smem, li, j0, qdesc[q]);
+                    __syncthreads();
+                    g = base;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        unsigned mk = info[h] & 0x3FFF;
+                        while (mk) {
+                            mk &= mk - 1;
+                            if (g / SWEEP_Q == rho) {
+                                const double rt = qres[g % SWEEP_Q];
+                                if (rt >= 0.0) { mainv[h] = mainv[h] + rt; ++cnt[h]; }
+                            }
+                            ++g;
+                        }
+                    }
+                }
+            }
+            // ---- phase C: canonical reduction (pair, wave butterfly, chunk merge) ------------------
+            const int kind0 = (info[0] >> 20) & 3, kind1 = (info[1] >> 20) & 3;
+            double s1 = (kind0 == 1 ? mainv[0] : 0.0) + (kind1 == 1 ? mainv[1] : 0.0);
+            double s2 = (kind0 == 2 ? mainv[0] : 0.0) + (kind1 == 2 ? mainv[1] : 0.0);
+            double s0 = depv[0] + depv[1];
+            int cpack = (int)((info[0] >> 19) & 1) + (int)((info[1] >> 19) & 1)
+                      + (((kind0 == 1 ? cnt[0] : 0) + (kind1 == 1 ? cnt[1] : 0)) << 8)
+                      + (((kind0 == 2 ? cnt[0] : 0) + (kind1 == 2 ? cnt[1] : 0)) << 19);
+            if (top) s0 = wave_tree_sum(s0);
+            s1 = wave_tree_sum(s1);
+            s2 = wave_tree_sum(s2);
+            cpack = wave_sum_i(cpack);
+            c0[rr] += cpack & 0xFF; c1[rr] += (cpack >> 8) & 0x7FF; c2[rr] += (cpack >> 19) & 0x7FF;
+            row0[rr] = stack_push(stk0[rr], s0, m);
+            row1[rr] = stack_push(stk1[rr], s1, m);
+            row2[rr] = stack_push(stk2[rr], s2, m);
+        }
+        if (lane == 0 && j < S.L) {
+            const int64_t o = (int64_t)lp * 3 * S.L + j;
+            S.rowsum[o] = row0[rr]; S.rowsum[o + S.L] = row1[rr]; S.rowsum[o + 2 * S.L] = row2[rr];
+            S.rowcnt[o] = c0[rr]; S.rowcnt[o + S.L] = c1[rr]; S.rowcnt[o + 2 * S.L] = c2[rr];
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// k_sweep_march (variant 2, default): 2.5-D blocking.  One block owns SWEEP_TJ rows and
+// marches over MARCH_NI consecutive planes, keeping a 5-plane ring of the u16 census-class
+// array in LDS (each class word is fetched ~1.5x instead of 7.5x).  A lane handles 4
+// consecutive voxels of a row: the 14-neighbour census (#in-bounds, #empty, #W/Re/C, #Re/C)
+// of all 4 voxels is 17 LDS loads + SWAR adds on packed 4-bit counters -- no compares.
+// T is streamed once (32 B per lane).  Interface events (attachment/diffusion) go through
+// the block-wide item queue as in variant 1; voxel sums are accumulated in slot order, so
+// row sums are bit-identical to the simple kernel and to the oracle's canonical tree.
+// ----------------------------------------------------------------------------------------
+constexpr int MARCH_NI = 8;     // planes per block
+constexpr int MARCH_Q = 1024;   // item-queue capacity per round
+constexpr int MARCH_MAXCH = 4;  // chunks of 256 voxels per row (L <= 1024)
+
+// Everything the hot part of k_sweep_march needs, by value (stays in SGPRs); the rare
+// interface-event path reads the full KParams/SlabView through pointers instead.
+struct MarchArgs {
+    double T_melt, delta_T_c, kT, I0, rate_threshold, nu_dep;
+    int L, gi0, nloc, RJ, pitchC, pitchT, Pk;
+    const uint16_t* cls;
+    const double* T;
+    double* rowsum;
+    int32_t* rowcnt;
+};
+
+__device__ __noinline__ double march_item_rate(const KParams* __restrict__ Pg, const SlabView* __restrict__ Sg,
+                                               int li, int j0, unsigned desc)
+{
+    const KParams P = *Pg;
+    const SlabView S = *Sg;
+    const int r = desc & 7, k = (desc >> 3) & 1023, m = (desc >> 13) & 15, n_bonds = (desc >> 17) & 15;
+    const int j = j0 + r;
+    const int di = nbi_rt(m), dj = nbj_rt(m), dk = nbk_rt(m);
+    const int st = S.state[S.sidx(li, j, k)];
+    const double Tc = pymax(S.T[S.tidx(li, j, k)], 1.0);
+    double rate;
+    if (st == 0) rate = att_rate(P, S, li, j, k, di, dj, dk, S.state[S.sidx(li + di, j + dj, k + dk)], Tc);
+    else rate = diff_rate(P, S, li, j, k, di, dj, dk, st, n_bonds, Tc);
+    return (rate > P.rate_threshold && finite_d(rate)) ? rate : -1.0;
+}
+
+// item descriptors of one voxel (rare path): which neighbour slots are sources / free sites
+__device__ __noinline__ int march_push_items(const SlabView* __restrict__ Sg, unsigned* qdesc, int li, int j, int r, int k,
+                                             bool want_src, unsigned n_bonds, int g, int rho)
+{
+    const SlabView S = *Sg;
+#pragma unroll 1
+    for (int mm = 0; mm < 14; ++mm) {
+        const int sm = S.state[S.sidx(li + nbi_rt(mm), j + nbj_rt(mm), k + nbk_rt(mm))];
+        const bool hit = want_src ? (sm >= 1 && sm <= 3) : (sm == 0);
+        if (hit) {
+            if (g / MARCH_Q == rho)
+                qdesc[g % MARCH_Q] = (unsigned)r | ((unsigned)k << 3) | ((unsigned)mm << 13) | (n_bonds << 17);
+            ++g;
+        }
+    }
+    return g;
+}
+
+__device__ __forceinline__ unsigned alignbit16(unsigned hi, unsigned lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
+
+__global__ __launch_bounds__(256) void k_sweep_march(MarchArgs A, const KParams* __restrict__ Pg,
+                                                     const SlabView* __restrict__ Sg, const double* __restrict__ ktab_g,
+                                                     const StepState* __restrict__ ss)
+{
+    if (ss && ss->status) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TJ = SWEEP_TJ, TR = TJ + 4;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int L = A.L;
+    const int njt = (L + TJ - 1) / TJ;
+    const int nib = (A.nloc + MARCH_NI - 1) / MARCH_NI;
+    const int nblk = njt * nib;
+    int b = blockIdx.x;
+    if ((nblk & 7) == 0) b = (b & 7) * (nblk >> 3) + (b >> 3);   // contiguous block ranges per XCD
+    const int ib = b / njt, jt = b - ib * njt;
+    const int j0 = jt * TJ;
+    const int lp0 = ib * MARCH_NI, lp1 = min(lp0 + MARCH_NI, A.nloc);
+    const int pitchC = A.pitchC;
+    const int slab = TR * pitchC;                                     // u16 per plane slab
+    uint16_t* ring = reinterpret_cast<uint16_t*>(smem);
+    const int ring_bytes = (5 * slab * 2 + 15) & ~15;
+    double* ktab = reinterpret_cast<double*>(smem + ring_bytes);      // [226]
+    double* qres = ktab + 226;                                        // [MARCH_Q]
+    double* rowpart = qres + MARCH_Q;                                 // [TJ][3][MARCH_MAXCH]
+    unsigned* qdesc = reinterpret_cast<unsigned*>(rowpart + TJ * 3 * MARCH_MAXCH);   // [MARCH_Q]
+    int* wave_tot = reinterpret_cast<int*>(qdesc + MARCH_Q);          // [4]
+
+    const int cpr = pitchC >> 3;                                      // 16-B chunks per class row
+    auto load_slab = [&](int lsrc) {
+        const uint4* src = reinterpret_cast<const uint4*>(A.cls + ((int64_t)lsrc * A.RJ + j0) * pitchC);
+        uint4* dst = reinterpret_cast<uint4*>(ring + (lsrc % 5) * slab);
+        for (int idx = tid; idx < TR * cpr; idx += 256) dst[idx] = src[idx];
+    };
+    for (int d = 0; d < 4; ++d) load_slab(lp0 + d);                   // planes li-2 .. li+1 of the first plane
+    if (tid < 225) ktab[tid] = ktab_g[tid];
+
+    const int nch = A.Pk > 256 ? (A.Pk >> 8) : 1;
+#pragma unroll 1
+    for (int lp = lp0; lp < lp1; ++lp) {
+        const int li = lp + 2, i = A.gi0 + lp;
+        const bool top = (i == L - 1);
+        load_slab(li + 2);
+        __syncthreads();
+        int so[5];
+#pragma unroll
+        for (int d = 0; d < 5; ++d) so[d] = ((li - 2 + d) % 5) * slab;
+#pragma unroll 1
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = w + 4 * rr, j = j0 + r;
+            int cdep = 0, cdiff = 0, cemp = 0;
+#pragma unroll 1
+            for (int m = 0; m < nch; ++m) {
+                const int k0 = (m << 8) + 4 * lane;
+                double mainv[4] = {0.0, 0.0, 0.0, 0.0};
+                unsigned info[4] = {0u, 0u, 0u, 0u};   // [1:0] kind 1 diff / 2 empty, [2] main valid, [6:3] #items, [10:7] n_bonds
+                double deps = 0.0;
+                int nitems = 0;
+                if (j < L && k0 < L) {
+                    const double2 Ta = *reinterpret_cast<const double2*>(A.T + ((int64_t)li * L + j) * A.pitchT + k0);
+                    const double2 Tb = (k0 + 2 < L) ? *reinterpret_cast<const double2*>(A.T + ((int64_t)li * L + j) * A.pitchT + k0 + 2)
+                                                    : make_double2(0.0, 0.0);
+                    // ---- SWAR census of the 4 voxels' 14 neighbours ------------------------------
+                    auto rowp = [&](int d, int row) { return ring + so[d + 2] + row * pitchC + KOFFC + k0; };
+                    auto ld2 = [&](const uint16_t* p) { return *reinterpret_cast<const uint2*>(p); };
+                    auto ld1 = [&](const uint16_t* p) { return *reinterpret_cast<const unsigned*>(p); };
+                    uint2 acc = ld2(rowp(1, r + 3));
+                    uint2 t;
+                    t = ld2(rowp(1, r + 1)); acc.x += t.x; acc.y += t.y;
+                    t = ld2(rowp(-1, r + 3)); acc.x += t.x; acc.y += t.y;
+                    t = ld2(rowp(-1, r + 1)); acc.x += t.x; acc.y += t.y;
+                    t = ld2(rowp(2, r + 2)); acc.x += t.x; acc.y += t.y;
+                    t = ld2(rowp(-2, r + 2)); acc.x += t.x; acc.y += t.y;
+                    t = ld2(rowp(0, r + 4)); acc.x += t.x; acc.y += t.y;
+                    t = ld2(rowp(0, r + 0)); acc.x += t.x; acc.y += t.y;
+#pragma unroll
+                    for (int dj = -1; dj <= 1; dj += 2) {          // (0,dj,+-1): neighbours k-1 and k+1
+                        const uint16_t* p = rowp(0, r + 2 + dj);
+                        const unsigned Aw = ld1(p - 2), Cw = ld1(p + 4);
+                        const uint2 B = ld2(p);
+                        const unsigned m1 = alignbit16(B.x, Aw), m2 = alignbit16(B.y, B.x), m3 = alignbit16(Cw, B.y);
+                        acc.x += m1 + m2; acc.y += m2 + m3;
+                    }
+                    const uint16_t* po = rowp(0, r + 2);             // own row: neighbours k-2 and k+2
+                    const unsigned Aw = ld1(po - 2), Cw = ld1(po + 4);
+                    const uint2 own = ld2(po);
+                    acc.x += Aw + own.y; acc.y += own.x + Cw;
+                    // ---- cheap per-voxel part ----------------------------------------------------
+                    double dsum[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        const unsigned f = ((h < 2 ? acc.x : acc.y) >> (16 * (h & 1))) & 0xFFFFu;
+                        const unsigned oc = ((h < 2 ? own.x : own.y) >> (16 * (h & 1))) & 0xFFFFu;
+                        const int n_nb = f & 15, n_empty = (f >> 4) & 15, n_src = (f >> 8) & 15, n_imp = (f >> 12) & 15;
+                        if (oc & 0x10u) {                            // empty voxel
+                            const double Tc = pymax(h == 0 ? Ta.x : h == 1 ? Ta.y : h == 2 ? Tb.x : Tb.y, 1.0);
+                            unsigned inf = 2u | ((unsigned)n_src << 3);
+                            if (top) {
+                                const double rate = A.nu_dep * exp(-(A.T_melt - Tc) / (A.kT * Tc));
+                                if (finite_d(rate)) { dsum[h] = rate; ++cdep; }
+                            }
+                            const double dT = A.T_melt - Tc;
+                            if (dT > A.delta_T_c) {
+                                const double aa = dT + 1e-6;
+                                const double barrier = ktab[n_nb * 15 + n_imp] / pymax(aa * aa, 1e-6);
+                                const double rate = A.I0 * exp(-barrier / (A.kT * Tc));
+                                if (rate > A.rate_threshold && finite_d(rate)) { mainv[h] = rate; inf |= 4u; }
+                            }
+                            info[h] = inf;
+                            nitems += n_src;
+                        } else if (oc & 0x100u) {                    // W / Re / C atom
+                            info[h] = 1u | ((unsigned)n_empty << 3) | ((unsigned)(n_nb - n_empty) << 7);
+                            nitems += n_empty;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    deps = (dsum[0] + dsum[1]) + (dsum[2] + dsum[3]);
+                }
+                // ---- interface events through the block-wide item queue ----------------------------
+                int cnt[4];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) cnt[h] = (info[h] >> 2) & 1;
+                if (__syncthreads_or(nitems)) {
+                    int incl = nitems;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+                    if (lane == 63) wave_tot[w] = incl;
+                    __syncthreads();
+                    int base = incl - nitems, total = 0;
+#pragma unroll
+                    for (int ww = 0; ww < 4; ++ww) { const int t = wave_tot[ww]; if (ww < w) base += t; total += t; }
+                    const int nrounds = (total + MARCH_Q - 1) / MARCH_Q;
+#pragma unroll 1
+                    for (int rho = 0; rho < nrounds; ++rho) {
+                        if (rho) __syncthreads();
+                        if (nitems) {
+                            int g = base;
+#pragma unroll
+                            for (int h = 0; h < 4; ++h)
+                                if ((info[h] >> 3) & 15u)
+                                    g = march_push_items(Sg, qdesc, li, j, r, k0 + h, (info[h] & 3u) == 2u, (info[h] >> 7) & 15u, g, rho);
+                        }
+                        __syncthreads();
+                        const int nq = min(MARCH_Q, total - rho * MARCH_Q);
+#pragma unroll 1
+                        for (int q = tid; q < nq; q += 256) qres[q] = march_item_rate(Pg, Sg, li, j0, qdesc[q]);
+                        __syncthreads();
+                        if (nitems) {
+                            int g = base;
+#pragma unroll
+                            for (int h = 0; h < 4; ++h) {
+                                const int ni = (info[h] >> 3) & 15;
+                                for (int t = 0; t < ni; ++t, ++g) {
+                                    if (g / MARCH_Q == rho) {
+                                        const double rt = qres[g % MARCH_Q];
+                                        if (rt >= 0.0) { mainv[h] = mainv[h] + rt; ++cnt[h]; }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+                // ---- canonical reduction: 4-voxel tree, wave butterfly, chunk partial to LDS --------
+                double e[4], d[4];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const unsigned kind = info[h] & 3u;
+                    e[h] = (kind == 2u) ? mainv[h] : 0.0;
+                    d[h] = (kind == 1u) ? mainv[h] : 0.0;
+                    cemp += (kind == 2u) ? cnt[h] : 0;
+                    cdiff += (kind == 1u) ? cnt[h] : 0;
+                }
+                double s2 = (e[0] + e[1]) + (e[2] + e[3]);
+                double s1 = (d[0] + d[1]) + (d[2] + d[3]);
+                double s0 = deps;
+                if (__any(s2 != 0.0)) s2 = wave_tree_sum(s2);
+                if (__any(s1 != 0.0)) s1 = wave_tree_sum(s1);
+                if (top && __any(s0 != 0.0)) s0 = wave_tree_sum(s0);
+                if (lane == 0) {
+                    rowpart[(r * 3 + 0) * MARCH_MAXCH + m] = s0;
+                    rowpart[(r * 3 + 1) * MARCH_MAXCH + m] = s1;
+                    rowpart[(r * 3 + 2) * MARCH_MAXCH + m] = s2;
+                }
+            }
+            // ---- row totals: balanced tree over the chunk partials; counts reduced once ------------
+            const int n0 = wave_sum_i(cdep), n1 = wave_sum_i(cdiff), n2 = wave_sum_i(cemp);
+            if (lane == 0 && j < L) {
+                const int64_t o = (int64_t)lp * 3 * L + j;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    double* p = rowpart + (r * 3 + c) * MARCH_MAXCH;
+                    for (int n = nch; n > 1; n >>= 1)
+                        for (int t = 0; t < (n >> 1); ++t) p[t] = p[2 * t] + p[2 * t + 1];
+                    A.rowsum[o + (int64_t)c * L] = p[0];
+                }
+                A.rowcnt[o] = n0; A.rowcnt[o + L] = n1; A.rowcnt[o + 2 * L] = n2;
+            }
+        }
+        __syncthreads();   // ring slot (li-2)%5 is overwritten by the next plane's load
     }
 }
 
@@ -289,7 +738,7 @@ __global__ __launch_bounds__(256) void k_select(KParams P, const SlabView* __res
         double sum = 0.0; int cnt = 0;
         if (k < L) {
             const int st = S.state[S.sidx(li, j, k)];
-            auto nb = [&](int mm) -> int { return S.state[S.sidx(li + nbi(mm), j + nbj(mm), k + nbk(mm))]; };
+            auto nb = [&](int mm) -> int { return S.state[S.sidx(li + nbi_rt(mm), j + nbj_rt(mm), k + nbk_rt(mm))]; };
             auto emit = [&](int cat, int, double rate, int, int) { if (cat == c) { sum += rate; ++cnt; } };
             eval_voxel(P, S, ktab, li, i, j, k, st, S.T[S.tidx(li, j, k)], nb, emit);
         }
@@ -308,7 +757,7 @@ __global__ __launch_bounds__(256) void k_select(KParams P, const SlabView* __res
         bool found = false;
         int p_type = -1, p_m = -1, p_atom = 0;
         double p_rate = 0.0;
-        auto nb = [&](int mm) -> int { return S.state[S.sidx(li + nbi(mm), j + nbj(mm), k + nbk(mm))]; };
+        auto nb = [&](int mm) -> int { return S.state[S.sidx(li + nbi_rt(mm), j + nbj_rt(mm), k + nbk_rt(mm))]; };
         auto emit = [&](int cat, int type, double rate, int m, int atom) {
             if (cat != c || found) return;
             cum += rate;
@@ -324,9 +773,7 @@ __global__ __launch_bounds__(256) void k_select(KParams P, const SlabView* __res
         ev.dep_rank = (p_type == EV_DEP) ? rank : -1;
         ev.theta = 0.0; ev.phi = 0.0;
         if (p_m >= 0) {
-            int di = 0, dj = 0, dk = 0;
-#pragma unroll
-            for (int mm = 0; mm < 14; ++mm) if (mm == p_m) { di = nbi(mm); dj = nbj(mm); dk = nbk(mm); }
+            const int di = nbi_rt(p_m), dj = nbj_rt(p_m), dk = nbk_rt(p_m);
             ev.target[0] = i + di; ev.target[1] = j + dj; ev.target[2] = k + dk;
             // orientation carried by the event: diff moves the source's, att copies the neighbour's
             const int64_t q = (p_type == EV_DIFF) ? S.tidx(li, j, k) : S.tidx(li + di, j + dj, k + dk);
@@ -342,8 +789,10 @@ __device__ __forceinline__ void write_site(const SlabView& S, int i, int j, int 
     const int li = i - (S.gi0 - 2);
     if (li < 0 || li >= S.nloc + 4) return;
     S.state[S.sidx(li, j, k)] = (uint8_t)st;
+    S.cls[S.cidx(li, j, k)] = class16(st);
     const int64_t q = S.tidx(li, j, k);
     S.theta[q] = th; S.phi[q] = ph;
+    orient_vec(th, ph, S.ovec + 3 * q);
 }
 // kmc_simulation.py:276-327 on every local slab whose extended range holds the voxel(s)
 __device__ __forceinline__ void apply_event(const SlabView* slabs, int nslabs, const cetkmc_event& ev, int make_defect)
@@ -485,7 +934,7 @@ __global__ __launch_bounds__(256) void k_thermal(SlabView S, const double* __res
 // ---- layout conversion -----------------------------------------------------------------------
 // src: contiguous (nplanes, L, L) covering global planes [i_begin, i_begin+nplanes)
 template <class SRC>
-__global__ void k_pack_u8(SlabView S, uint8_t* dst, const SRC* __restrict__ src, int i_begin, int nplanes)
+__global__ void k_pack_u8(SlabView S, uint8_t* dst, const SRC* __restrict__ src, int i_begin, int nplanes, int with_cls)
 {
     const int L = S.L;
     const int64_t n = (int64_t)nplanes * L * L;
@@ -494,6 +943,7 @@ __global__ void k_pack_u8(SlabView S, uint8_t* dst, const SRC* __restrict__ src,
         int li = i - (S.gi0 - 2);
         if (li < 0 || li >= S.nloc + 4) continue;
         dst[S.sidx(li, j, k)] = (uint8_t)src[idx];
+        if (with_cls) S.cls[S.cidx(li, j, k)] = class16((int)(uint8_t)src[idx]);
     }
 }
 template <class DST>
@@ -514,6 +964,14 @@ __global__ void k_check_range(const int64_t* __restrict__ src, int64_t n, int lo
         if (src[idx] < lo || src[idx] > hi) *bad = 1;
 }
 
+// orientation unit vectors of every voxel of the slab (after theta/phi uploads)
+__global__ void k_orient(SlabView S)
+{
+    const int64_t n = (int64_t)(S.nloc + 4) * S.L * S.pitchT;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x)
+        orient_vec(S.theta[idx], S.phi[idx], S.ovec + 3 * idx);
+}
+
 // ---- event list materialisation ----------------------------------------------------------------
 // One thread per row (owned plane, category, j); offsets[] is the exclusive prefix of the row
 // counts in canonical order, computed on the host from the last sweep.
@@ -532,7 +990,7 @@ __global__ void k_enumerate(KParams P, SlabView S, const double* __restrict__ kt
     int64_t o = offsets[row];
     for (int k = 0; k < L; ++k) {
         const int st = S.state[S.sidx(li, j, k)];
-        auto nb = [&](int mm) -> int { return S.state[S.sidx(li + nbi(mm), j + nbj(mm), k + nbk(mm))]; };
+        auto nb = [&](int mm) -> int { return S.state[S.sidx(li + nbi_rt(mm), j + nbj_rt(mm), k + nbk_rt(mm))]; };
         auto emit = [&](int cat, int type, double rate, int m, int atom) {
             if (cat != c) return;
             if (o < cap) {
@@ -540,10 +998,7 @@ __global__ void k_enumerate(KParams P, SlabView S, const double* __restrict__ kt
                 ev.type = type; ev.pos[0] = i; ev.pos[1] = j; ev.pos[2] = k;
                 ev.target[0] = ev.target[1] = ev.target[2] = -1;
                 if (m >= 0) {
-                    int di = 0, dj = 0, dk = 0;
-#pragma unroll
-                    for (int mm = 0; mm < 14; ++mm) if (mm == m) { di = nbi(mm); dj = nbj(mm); dk = nbk(mm); }
-                    ev.target[0] = i + di; ev.target[1] = j + dj; ev.target[2] = k + dk;
+                    ev.target[0] = i + nbi_rt(m); ev.target[1] = j + nbj_rt(m); ev.target[2] = k + nbk_rt(m);
                 }
                 ev.atom = atom; ev.rate = rate; ev.dep_rank = -1; ev.theta = 0.0; ev.phi = 0.0;
                 out[o] = ev;

@@ -12,14 +12,26 @@ namespace cetkmc {
 
 constexpr int KOFF = 4;           // byte offset of k=0 inside a padded state row
 constexpr uint8_t OOB = 255;      // sentinel state outside the lattice
+constexpr int KOFFC = 4;          // u16 offset of k=0 inside a padded class row
+
+// Census class of a lattice state: four 4-bit counters-to-be.  Summing the class words of the
+// 14 neighbours gives, without any compare, [3:0] #in-bounds, [7:4] #empty, [11:8] #W/Re/C
+// (attachment sources), [15:12] #Re/C (nucleation impurities).  Out-of-lattice = 0.
+__host__ __device__ inline uint16_t class16(int st)
+{
+    if (st >= 128) return 0;
+    uint16_t c = 0x0001;
+    if (st == 0) c |= 0x0010;
+    if (st >= 1 && st <= 3) c |= 0x0100;
+    if (st == 2 || st == 3) c |= 0x1000;
+    return c;
+}
 constexpr int CAT_DEP = 0, CAT_DIFF = 1, CAT_EMPTY = 2;
 constexpr int EV_DEP = 0, EV_DIFF = 1, EV_NUC = 2, EV_ATT = 3;
 
-// kmc_event_rates.py:29-30,35 -- neighbour offsets in the reference's order.  constexpr
-// lookups so that fully unrolled loops fold them into immediates.
-__host__ __device__ constexpr int nbi(int m) { constexpr int t[14] = {1, 1, -1, -1, 0, 0, 0, 0, 2, -2, 0, 0, 0, 0}; return t[m]; }
-__host__ __device__ constexpr int nbj(int m) { constexpr int t[14] = {1, -1, 1, -1, 1, 1, -1, -1, 0, 0, 2, -2, 0, 0}; return t[m]; }
-__host__ __device__ constexpr int nbk(int m) { constexpr int t[14] = {0, 0, 0, 0, 1, -1, 1, -1, 0, 0, 0, 0, 2, -2}; return t[m]; }
+// kmc_event_rates.py:29-30,35 -- the 14 neighbour offsets, in the reference's order:
+//   (1,1,0),(1,-1,0),(-1,1,0),(-1,-1,0),(0,1,1),(0,1,-1),(0,-1,1),(0,-1,-1),
+//   (2,0,0),(-2,0,0),(0,2,0),(0,-2,0),(0,0,2),(0,0,-2)   -- see nbi_rt/nbj_rt/nbk_rt below.
 
 // Kernel-side copy of the rate constants (cetkmc_params, include/cetkmc.h).
 struct KParams {
@@ -41,15 +53,21 @@ struct SlabView {
     int pitchS;   // bytes per padded state row (k=0 at KOFF)
     int pitchT;   // doubles per T/theta/phi row
     int Pk;       // next_pow2(L)
+    int pitchC;   // u16 elements per padded class row (k=0 at KOFFC)
     uint8_t* state;     // [(nloc+4)][RJ][pitchS]
     uint8_t* defects;   // same layout
+    uint16_t* cls;      // [(nloc+4)][RJ][pitchC] neighbour-census class of every voxel (class16())
     double* T;          // [(nloc+4)][L][pitchT]  (current buffer)
     double* theta;
     double* phi;
+    double* ovec;       // [(nloc+4)][L][pitchT][3] orientation unit vectors (sin t cos p, sin t sin p, cos t)
     double* rowsum;     // [nloc*3][L]  row sums of the last sweep, index (lp*3+cat)*L + j
     int32_t* rowcnt;
     __device__ __forceinline__ int64_t sidx(int li, int j, int k) const {
         return ((int64_t)li * RJ + (j + 2)) * pitchS + KOFF + k;
+    }
+    __device__ __forceinline__ int64_t cidx(int li, int j, int k) const {
+        return ((int64_t)li * RJ + (j + 2)) * pitchC + KOFFC + k;
     }
     __device__ __forceinline__ int64_t tidx(int li, int j, int k) const {
         return ((int64_t)li * L + j) * pitchT + k;
@@ -71,6 +89,15 @@ __device__ __forceinline__ double k_eff(const KParams& P, int n_nb, int n_imp)
     return pymax(0.1 * P.K_nuc, pymin(P.K_nuc, K));
 }
 
+// kmc_event_rates.py:11-15: unit vector of an orientation (theta, phi)
+__device__ __forceinline__ void orient_vec(double t, double p, double* out)
+{
+    double st, ct, sp, cp;
+    sincos(t, &st, &ct);
+    sincos(p, &sp, &cp);
+    out[0] = st * cp; out[1] = st * sp; out[2] = ct;
+}
+
 // kmc_event_rates.py:9-23
 __device__ __forceinline__ double misorientation(double t1, double p1, double t2, double p2)
 {
@@ -80,6 +107,58 @@ __device__ __forceinline__ double misorientation(double t1, double p1, double t2
     double dot = v1x * v2x + v1y * v2y + v1z * v2z;
     dot = pymax(pymin(dot, 1.0), -1.0);
     return acos(dot);
+}
+
+// ---- rate primitives shared by every kernel (one expression order everywhere) ------------
+// neighbour offsets of a RUNTIME slot m (bit-packed, value+2 in 3 bits per slot)
+__device__ __forceinline__ int nbi_rt(int m) { return (int)((0x1248449225bULL >> (3 * m)) & 7ULL) - 2; }
+__device__ __forceinline__ int nbj_rt(int m) { return (int)((0x1211225b2cbULL >> (3 * m)) & 7ULL) - 2; }
+__device__ __forceinline__ int nbk_rt(int m) { return (int)((0x44922cb492ULL >> (3 * m)) & 7ULL) - 2; }
+
+// kmc_event_rates.py:60-63
+__device__ __forceinline__ double dep_rate(const KParams& P, double Tc)
+{
+    return P.nu_dep * exp(-(P.T_melt - Tc) / (P.kT * Tc));
+}
+// kmc_event_rates.py:126-130 with K_eff from the table
+__device__ __forceinline__ double nuc_rate(const KParams& P, double K, double dT, double kTT)
+{
+    double a = dT + 1e-6;
+    double barrier = K / pymax(a * a, 1e-6);
+    return P.I0 * exp(-barrier / kTT);
+}
+// kmc_event_rates.py:147-156: attachment of species sn from neighbour slot m to empty voxel (li,j,k).
+// The orientation unit vectors (compute_misorientation, :11-20) are kept per voxel in S.ovec
+// (written whenever theta/phi change), so the hot kernels need no sin/cos; and since
+// cos(arccos(d)) == d to 1 ulp, E_att = 0.5*E_b*(1 - cos(mis)) is evaluated as 0.5*E_b*(1 - d)
+// with d the clamped dot product (:21-22).  Rates agree with the reference to ~1e-15 relative.
+__device__ __forceinline__ double att_rate(const KParams& P, const SlabView& S, int li, int j, int k,
+                                           int di, int dj, int dk, int sn, double Tc)
+{
+    const int L = S.L;
+    const double* a = S.ovec + 3 * S.tidx(li, j, k);
+    const double* b = S.ovec + 3 * S.tidx(li + di, j + dj, k + dk);
+    double dot = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+    dot = pymax(pymin(dot, 1.0), -1.0);
+    const int km = k - 1 > 0 ? k - 1 : 0;
+    const int kp = k + 1 < L - 1 ? k + 1 : L - 1;
+    const double grad_z = (S.T[S.tidx(li, j, kp)] - S.T[S.tidx(li, j, km)]) * 0.5;
+    const double gf = pymax(0.0, grad_z) / pymax(P.T_melt - Tc, 1.0);
+    const double E_att = 0.5 * P.E_b[sn - 1] * (1.0 - dot);
+    return P.nu * exp(-E_att / (P.kT * Tc)) * (1.0 + P.anisotropy * gf);
+}
+// kmc_event_rates.py:93-107: diffusion of the atom st at (li,j,k) into the empty neighbour slot
+__device__ __forceinline__ double diff_rate(const KParams& P, const SlabView& S, int li, int j, int k,
+                                            int di, int dj, int dk, int st, int n_bonds, double Tc)
+{
+    const int ia = (st == 1) ? 0 : (st == 2) ? 1 : 2;
+    const double defect_factor = 1.0 + (double)S.defects[S.sidx(li, j, k)];
+    const double E_tot = pymax(P.E_diff[ia] + 0.1 * (double)n_bonds * P.E_b[ia], 0.0);
+    const double Tn = pymax(S.T[S.tidx(li + di, j + dj, k + dk)], 1.0);
+    const double dTn = fabs(Tc - Tn);
+    const double denom = pymax(P.T_melt - Tn, 1.0);
+    const double grad = 1.0 + 0.1 * dTn / denom;
+    return P.nu * grad * exp(-defect_factor * E_tot / (P.kT * Tc));
 }
 
 // Evaluate the events of voxel (i,j,k) (local plane li) whose own state is `st` and raw
@@ -99,72 +178,44 @@ __device__ __forceinline__ void eval_voxel(const KParams& P, const SlabView& S, 
     const double Tc = pymax(Traw, 1.0);
     if (st == 0) {
         if (i == S.L - 1) {
-            double rate = P.nu_dep * exp(-(P.T_melt - Tc) / (P.kT * Tc));
+            double rate = dep_rate(P, Tc);
             if (finite_d(rate)) emit(CAT_DEP, EV_DEP, rate, -1, 0);
         }
-        int s[14];
-        int n_nb = 0, n_imp = 0, n_src = 0;
+        int n_nb = 0, n_imp = 0;
+        unsigned m_src = 0;
 #pragma unroll
         for (int m = 0; m < 14; ++m) {
-            s[m] = nb(m);
-            n_nb += (s[m] != OOB);
-            n_imp += (s[m] == 2 || s[m] == 3);
-            n_src += (s[m] >= 1 && s[m] <= 3);
+            const int sm = nb(m);
+            n_nb += (sm != OOB);
+            n_imp += (sm == 2 || sm == 3);
+            if (sm >= 1 && sm <= 3) m_src |= 1u << m;
         }
         const double dT = P.T_melt - Tc;
-        const double kTT = P.kT * Tc;
         if (dT > P.delta_T_c) {
-            double K = ktab[n_nb * 15 + n_imp];
-            double a = dT + 1e-6;
-            double barrier = K / pymax(a * a, 1e-6);
-            double rate = P.I0 * exp(-barrier / kTT);
+            double rate = nuc_rate(P, ktab[n_nb * 15 + n_imp], dT, P.kT * Tc);
             if (rate > P.rate_threshold && finite_d(rate)) emit(CAT_EMPTY, EV_NUC, rate, -1, 1);
         }
-        if (n_src > 0) {
-            const int L = S.L;
-            const int64_t c = S.tidx(li, j, k);
-            const double th0 = S.theta[c], ph0 = S.phi[c];
-            const int km = k - 1 > 0 ? k - 1 : 0;
-            const int kp = k + 1 < L - 1 ? k + 1 : L - 1;
-            const double grad_z = (S.T[S.tidx(li, j, kp)] - S.T[S.tidx(li, j, km)]) * 0.5;
-            const double gf = pymax(0.0, grad_z) / pymax(dT, 1.0);
-            const double aniso = 1.0 + P.anisotropy * gf;
-#pragma unroll
-            for (int m = 0; m < 14; ++m) {
-                if (s[m] >= 1 && s[m] <= 3) {
-                    int64_t q = S.tidx(li + nbi(m), j + nbj(m), k + nbk(m));
-                    double mis = misorientation(th0, ph0, S.theta[q], S.phi[q]);
-                    double E_att = 0.5 * P.E_b[s[m] - 1] * (1.0 - cos(mis));
-                    double rate = P.nu * exp(-E_att / kTT) * aniso;
-                    if (rate > P.rate_threshold && finite_d(rate)) emit(CAT_EMPTY, EV_ATT, rate, m, s[m]);
-                }
-            }
+        while (m_src) {
+            const int m = __builtin_ctz(m_src);
+            m_src &= m_src - 1;
+            const int sm = nb(m);
+            double rate = att_rate(P, S, li, j, k, nbi_rt(m), nbj_rt(m), nbk_rt(m), sm, Tc);
+            if (rate > P.rate_threshold && finite_d(rate)) emit(CAT_EMPTY, EV_ATT, rate, m, sm);
         }
     } else if (st != 4) {
-        int s[14];
-        int n_bonds = 0, n_empty = 0;
+        int n_bonds = 0;
+        unsigned m_empty = 0;
 #pragma unroll
         for (int m = 0; m < 14; ++m) {
-            s[m] = nb(m);
-            n_bonds += (s[m] != 0 && s[m] != OOB);
-            n_empty += (s[m] == 0);
+            const int sm = nb(m);
+            n_bonds += (sm != 0 && sm != OOB);
+            if (sm == 0) m_empty |= 1u << m;
         }
-        if (n_empty > 0) {
-            const int ia = (st == 1) ? 0 : (st == 2) ? 1 : 2;
-            const double defect_factor = 1.0 + (double)S.defects[S.sidx(li, j, k)];
-            const double E_tot = pymax(P.E_diff[ia] + 0.1 * (double)n_bonds * P.E_b[ia], 0.0);
-            const double arr = exp(-defect_factor * E_tot / (P.kT * Tc));
-#pragma unroll
-            for (int m = 0; m < 14; ++m) {
-                if (s[m] == 0) {
-                    double Tn = pymax(S.T[S.tidx(li + nbi(m), j + nbj(m), k + nbk(m))], 1.0);
-                    double dTn = fabs(Tc - Tn);
-                    double denom = pymax(P.T_melt - Tn, 1.0);
-                    double grad = 1.0 + 0.1 * dTn / denom;
-                    double rate = P.nu * grad * arr;
-                    if (rate > P.rate_threshold && finite_d(rate)) emit(CAT_DIFF, EV_DIFF, rate, m, st);
-                }
-            }
+        while (m_empty) {
+            const int m = __builtin_ctz(m_empty);
+            m_empty &= m_empty - 1;
+            double rate = diff_rate(P, S, li, j, k, nbi_rt(m), nbj_rt(m), nbk_rt(m), st, n_bonds, Tc);
+            if (rate > P.rate_threshold && finite_d(rate)) emit(CAT_DIFF, EV_DIFF, rate, m, st);
         }
     }
 }

@@ -127,6 +127,8 @@ int cetkmc_create_rank(const cetkmc_params* p, int L, int rank, int nranks, int 
 int cetkmc_destroy(void* handle);
 int cetkmc_set_params(void* handle, const cetkmc_params* p);
 int cetkmc_sync(void* handle);
+/* tuning / A-B switches: "sweep_variant" 0 = simple kernel, 1 = queued interface events (default) */
+int cetkmc_set_option(void* handle, const char* key, int64_t value);
 /* planes [*i0,*i1) owned by this handle (whole lattice unless created with create_rank) */
 int cetkmc_owned_planes(void* handle, int* i0, int* i1);
 

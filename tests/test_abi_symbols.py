@@ -53,8 +53,10 @@ def test_no_cpu_fallback():
 
 
 def test_product_never_imports_oracle():
+    """The product may MENTION the oracle in comments, but never imports, links or calls it."""
+    pat = re.compile(r"import\s+oracle|from\s+oracle|oracle\.|oracle/|libcet_oracle|\borc_[a-z_]+\s*\(")
     for dirpath, _, files in os.walk(PKG):
         for f in files:
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
-                assert "oracle" not in src.replace("# oracle", ""), os.path.join(dirpath, f)
+                assert not pat.search(src), os.path.join(dirpath, f)

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""A/B of the rate-sweep kernel variants in ONE process (interleaved rounds), plus a
+bit-exactness cross-check of their row sums.  GPU box only."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "cet-driven-simulation-for-3d-printing-am-kmc-approach_amd"))
+import cetkmc  # noqa: E402
+from cetkmc import synthetic  # noqa: E402
+
+L = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else "2,1,0".split(","))]
+rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+e = cetkmc.Engine(L, impurity_c=0.2)
+st, th, ph, T, df = synthetic.planes(L, 0, L, seed=42)
+e.upload_planes(0, L, st, th, ph, T, df)
+ref = None
+for v in variants:
+    e.set_option("sweep_variant", v)
+    info = e.rate_sweep()
+    rs, rc = e.row_sums()
+    if ref is None:
+        ref = (info, rs, rc)
+    else:
+        ok = info == ref[0] and np.array_equal(rs, ref[1]) and np.array_equal(rc, ref[2])
+        print(f"variant {v} vs {variants[0]}: bit-identical={ok}  info={info}", flush=True)
+print("info", ref[0], flush=True)
+res = {v: [] for v in variants}
+for r in range(rounds):
+    for v in variants:
+        e.set_option("sweep_variant", v)
+        n = 5 if v == 0 else 30
+        e.time_sweeps(2)
+        res[v].append(e.time_sweeps(n) / n)
+for v in variants:
+    ms = np.array(res[v])
+    print(f"variant {v}: sweep+reduce median {np.median(ms)*1e3:.1f} us  min {ms.min()*1e3:.1f} us  ({L}^3)", flush=True)
