@@ -25,7 +25,7 @@ def planes(L, i_begin, i_end, seed=42, constant_T=None, fill_frac=0.25):
         T = np.broadcast_to(ramp[None, None, :], (n, L, L)).copy()
     else:
         T = np.full((n, L, L), float(constant_T))
-    for p in range(n):
+    for p in range(n if kfill > 0 else 0):
         rs = np.random.RandomState((seed * 1000003 + (i_begin + p)) % (2 ** 32))
         sp = rs.choice(np.array([1, 2, 3], np.uint8), size=(L, kfill), p=[0.7, 0.1, 0.2])
         dmask = rs.random_sample((L, kfill)) < 0.005

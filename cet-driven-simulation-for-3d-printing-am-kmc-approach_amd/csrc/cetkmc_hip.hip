@@ -117,8 +117,9 @@ struct Handle {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
     bool swept = false;
-    int sweep_variant = 2;
-    size_t shmem_march = 0;
+    int sweep_variant = 1;
+    int ifc_blocks = 2048;     // grid of k_interface (grid-stride over the device-side list length)
+    size_t shmem_stream = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> prof;
 };
@@ -197,10 +198,9 @@ int create_common(const cetkmc_params* p, int L, const std::vector<std::pair<int
     h->pitchS = round_up(KOFF + L + 4, 16);
     h->pitchT = round_up(L, 2);
     h->pitchC = round_up(KOFFC + L + 8, 8);
-    h->shmem_march = (size_t)((5 * (SWEEP_TJ + 4) * h->pitchC * 2 + 15) & ~15) + (226 + MARCH_Q + SWEEP_TJ * 3 * MARCH_MAXCH) * sizeof(double)
-                     + MARCH_Q * sizeof(unsigned) + 4 * sizeof(int);
-    if (h->shmem_march > 160 * 1024) { delete h; return fail("L too large for the LDS ring"); }
-    HIPCHK(hipFuncSetAttribute((const void*)k_sweep_march, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->shmem_march));
+    h->shmem_stream = (size_t)((5 * (SWEEP_TJ + 4) * h->pitchC * 2 + 15) & ~15) + (226 + SWEEP_TJ * 3 * STREAM_MAXCH) * sizeof(double);
+    if (h->shmem_stream > 160 * 1024) { delete h; return fail("L too large for the LDS ring"); }
+    HIPCHK(hipFuncSetAttribute((const void*)k_sweep_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->shmem_stream));
     h->dev = dev; h->G = G; h->my_first = my_first;
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&h->ev0));
@@ -232,6 +232,15 @@ int create_common(const cetkmc_params* p, int L, const std::vector<std::pair<int
         HIPCHK(hipMemsetAsync(s.v.theta, 0, s.nT * sizeof(double), h->stream));
         HIPCHK(hipMemsetAsync(s.v.phi, 0, s.nT * sizeof(double), h->stream));
         HIPCHK(hipMalloc((void**)&s.v.ovec, 3 * s.nT * sizeof(double)));
+        HIPCHK(hipMalloc((void**)&s.v.ifc_val, s.nT * sizeof(double)));
+        HIPCHK(hipMalloc((void**)&s.v.ifc_cnt, s.nT));
+        HIPCHK(hipMalloc((void**)&s.v.ifc_in, s.nT));
+        HIPCHK(hipMalloc((void**)&s.v.ifc_list, (size_t)r.second * L * L * sizeof(uint32_t)));
+        HIPCHK(hipMalloc((void**)&s.v.ifc_n, sizeof(int)));
+        HIPCHK(hipMemsetAsync(s.v.ifc_val, 0, s.nT * sizeof(double), h->stream));
+        HIPCHK(hipMemsetAsync(s.v.ifc_cnt, 0, s.nT, h->stream));
+        HIPCHK(hipMemsetAsync(s.v.ifc_in, 0, s.nT, h->stream));
+        HIPCHK(hipMemsetAsync(s.v.ifc_n, 0, sizeof(int), h->stream));
         HIPCHK(hipMalloc((void**)&s.v.rowsum, (size_t)r.second * 3 * L * sizeof(double)));
         HIPCHK(hipMalloc((void**)&s.v.rowcnt, (size_t)r.second * 3 * L * sizeof(int32_t)));
         HIPCHK(hipMemsetAsync(s.v.rowsum, 0, (size_t)r.second * 3 * L * sizeof(double), h->stream));
@@ -336,6 +345,9 @@ int upload_impl(Handle* h, int i_begin, int i_end, const I* state, const double*
         if (state) {
             CHK(h2d_u8<I>(h, s, s.v.state, state, i_begin, a, b, true, 1));
             HIPCHK(hipMemcpyAsync(s.prev, s.v.state, s.nS, hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(hipMemsetAsync(s.v.ifc_in, 0, s.nT, h->stream));
+            HIPCHK(hipMemsetAsync(s.v.ifc_n, 0, sizeof(int), h->stream));
+            hipLaunchKernelGGL(k_ifc_rebuild, dim3(2048), dim3(256), 0, h->stream, s.v);
         }
         if (defects) CHK(h2d_u8<I>(h, s, s.v.defects, defects, i_begin, a, b, true));
         if (theta) CHK(h2d_f64(h, s, s.v.theta, theta, i_begin, a, b));
@@ -369,27 +381,28 @@ int download_impl(Handle* h, int i_begin, int i_end, I* state, double* theta, do
 int launch_sweep(Handle* h, bool batch, hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr)
 {
     const int TR = SWEEP_TJ + 4;
-    const size_t tile = (size_t)((5 * TR * h->pitchS + 15) & ~15);
-    const size_t shmem0 = tile + 225 * sizeof(double);
-    const size_t shmem1 = tile + 226 * sizeof(double) + (size_t)SWEEP_Q * (sizeof(double) + sizeof(unsigned)) + 4 * sizeof(int);
+    const size_t shmem0 = (size_t)((5 * TR * h->pitchS + 15) & ~15) + 225 * sizeof(double);
     const StepState* ss = batch ? h->d_ss : nullptr;
     const int njt = (h->L + SWEEP_TJ - 1) / SWEEP_TJ;
+    if (h->sweep_variant == 1) {
+        for (size_t s = 0; s < h->slabs.size(); ++s)
+            hipLaunchKernelGGL(k_interface, dim3(h->ifc_blocks), dim3(256), 0, h->stream, h->kp, view_of(h, (int)s), h->d_ktab, ss);
+    }
     if (ev_a) HIPCHK(hipEventRecord(ev_a, h->stream));
     for (size_t s = 0; s < h->slabs.size(); ++s) {
         SlabView v = view_of(h, (int)s);
-        if (h->sweep_variant == 2) {
-            const int nib = (v.nloc + MARCH_NI - 1) / MARCH_NI;
-            MarchArgs ma{};
-            ma.T_melt = h->kp.T_melt; ma.delta_T_c = h->kp.delta_T_c; ma.kT = h->kp.kT; ma.I0 = h->kp.I0;
-            ma.rate_threshold = h->kp.rate_threshold; ma.nu_dep = h->kp.nu_dep;
-            ma.L = v.L; ma.gi0 = v.gi0; ma.nloc = v.nloc; ma.RJ = v.RJ; ma.pitchC = v.pitchC; ma.pitchT = v.pitchT; ma.Pk = v.Pk;
-            ma.cls = v.cls; ma.T = v.T; ma.rowsum = v.rowsum; ma.rowcnt = v.rowcnt;
-            hipLaunchKernelGGL(k_sweep_march, dim3(nib * njt), dim3(256), h->shmem_march, h->stream, ma,
-                               (const KParams*)h->d_kp, (const SlabView*)(h->d_views[h->cur] + s), h->d_ktab, ss);
-        } else if (h->sweep_variant == 0)
+        if (h->sweep_variant == 1) {
+            StreamArgs sa{};
+            sa.T_melt = h->kp.T_melt; sa.delta_T_c = h->kp.delta_T_c; sa.kT = h->kp.kT; sa.I0 = h->kp.I0;
+            sa.rate_threshold = h->kp.rate_threshold; sa.nu_dep = h->kp.nu_dep;
+            sa.L = v.L; sa.gi0 = v.gi0; sa.nloc = v.nloc; sa.RJ = v.RJ; sa.pitchC = v.pitchC; sa.pitchT = v.pitchT; sa.Pk = v.Pk;
+            sa.cls = v.cls; sa.T = v.T; sa.ifc_val = v.ifc_val; sa.ifc_cnt = v.ifc_cnt; sa.rowsum = v.rowsum; sa.rowcnt = v.rowcnt;
+            const int nib = (v.nloc + STREAM_NI - 1) / STREAM_NI;
+            sa.group_first = 0; sa.group_count = nib;
+            hipLaunchKernelGGL(k_sweep_stream, dim3(nib * njt), dim3(256), h->shmem_stream, h->stream, sa, h->d_ktab, ss);
+        } else {
             hipLaunchKernelGGL(k_sweep_simple, dim3(v.nloc * njt), dim3(256), shmem0, h->stream, h->kp, v, h->d_ktab, ss);
-        else
-            hipLaunchKernelGGL(k_sweep, dim3(v.nloc * njt), dim3(256), shmem1, h->stream, h->kp, v, h->d_ktab, ss);
+        }
     }
     if (ev_b) HIPCHK(hipEventRecord(ev_b, h->stream));
     for (size_t s = 0; s < h->slabs.size(); ++s) {
@@ -492,6 +505,7 @@ void destroy_impl(Handle* h)
         (void)hipFree(s.v.state); (void)hipFree(s.v.defects); (void)hipFree(s.prev); (void)hipFree(s.v.cls);
         (void)hipFree(s.Tbuf[0]); (void)hipFree(s.Tbuf[1]); (void)hipFree(s.v.theta); (void)hipFree(s.v.phi); (void)hipFree(s.v.ovec);
         (void)hipFree(s.v.rowsum); (void)hipFree(s.v.rowcnt);
+        (void)hipFree(s.v.ifc_val); (void)hipFree(s.v.ifc_cnt); (void)hipFree(s.v.ifc_in); (void)hipFree(s.v.ifc_list); (void)hipFree(s.v.ifc_n);
     }
     void* ptrs[] = {h->d_views[0], h->d_views[1], h->d_blocks, h->d_events_all, h->d_ss, h->d_ktab, h->d_kp, h->d_scratch,
                     h->d_flag, h->d_qtop, h->d_u_pick, h->d_u_defect, h->d_u_np, h->d_q, h->d_log_total,
@@ -589,7 +603,7 @@ int cetkmc_set_option(void* handle, const char* key, int64_t value)
     Handle* h = (Handle*)handle;
     if (!h || !key) return fail("null argument");
     if (!strcmp(key, "sweep_variant")) {
-        if (value < 0 || value > 2) return fail("sweep_variant must be 0 (simple), 1 (queued) or 2 (marching, default)");
+        if (value < 0 || value > 1) return fail("sweep_variant must be 0 (simple) or 1 (streaming, default)");
         h->sweep_variant = (int)value;
         return 0;
     }
@@ -669,6 +683,9 @@ int cetkmc_set_prev_state(void* handle, const int64_t* prev_state)
             CHK(h2d_u8<int64_t>(h, s, s.prev, prev_state, 0, a, b, true));
         } else {
             HIPCHK(hipMemcpyAsync(s.prev, s.v.state, s.nS, hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(hipMemsetAsync(s.v.ifc_in, 0, s.nT, h->stream));
+            HIPCHK(hipMemsetAsync(s.v.ifc_n, 0, sizeof(int), h->stream));
+            hipLaunchKernelGGL(k_ifc_rebuild, dim3(2048), dim3(256), 0, h->stream, s.v);
         }
     }
     HIPCHK(hipStreamSynchronize(h->stream));

@@ -44,16 +44,47 @@ struct BatchCfg {
 constexpr int SWEEP_TJ = 8;        // rows of one plane per sweep block
 constexpr int PMAX = 2048;         // max leaves of an LDS heap tree (3L <= PMAX)
 
+// Balanced binary tree over the 64 lanes, result in every lane.  Levels 1,2 use quad_perm DPP,
+// levels 4,8 row_half_mirror / row_mirror DPP (the partner lane holds the sibling subtree's sum),
+// levels 16,32 the gfx950 v_permlane16_swap / v_permlane32_swap -- no LDS round trips.
+__device__ __forceinline__ double dpp_f64(double v, int ctrl_sel)
+{
+    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    unsigned a, b;
+    if (ctrl_sel == 0) { a = __builtin_amdgcn_update_dpp(0u, lo, 0xB1, 0xF, 0xF, false); b = __builtin_amdgcn_update_dpp(0u, hi, 0xB1, 0xF, 0xF, false); }
+    else if (ctrl_sel == 1) { a = __builtin_amdgcn_update_dpp(0u, lo, 0x4E, 0xF, 0xF, false); b = __builtin_amdgcn_update_dpp(0u, hi, 0x4E, 0xF, 0xF, false); }
+    else if (ctrl_sel == 2) { a = __builtin_amdgcn_update_dpp(0u, lo, 0x141, 0xF, 0xF, false); b = __builtin_amdgcn_update_dpp(0u, hi, 0x141, 0xF, 0xF, false); }
+    else { a = __builtin_amdgcn_update_dpp(0u, lo, 0x140, 0xF, 0xF, false); b = __builtin_amdgcn_update_dpp(0u, hi, 0x140, 0xF, 0xF, false); }
+    return __hiloint2double((int)b, (int)a);
+}
 __device__ __forceinline__ double wave_tree_sum(double v)
 {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) v = v + __shfl_xor(v, o, 64);
+    v = v + dpp_f64(v, 0);
+    v = v + dpp_f64(v, 1);
+    v = v + dpp_f64(v, 2);
+    v = v + dpp_f64(v, 3);
+    {
+        const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+        const auto r0 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto r1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __hiloint2double((int)r1[0], (int)r0[0]) + __hiloint2double((int)r1[1], (int)r0[1]);
+    }
+    {
+        const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+        const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = __hiloint2double((int)r1[0], (int)r0[0]) + __hiloint2double((int)r1[1], (int)r0[1]);
+    }
     return v;
 }
 __device__ __forceinline__ int wave_sum_i(int v)
 {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) v = v + __shfl_xor(v, o, 64);
+    v += (int)__builtin_amdgcn_update_dpp(0u, (unsigned)v, 0xB1, 0xF, 0xF, false);
+    v += (int)__builtin_amdgcn_update_dpp(0u, (unsigned)v, 0x4E, 0xF, 0xF, false);
+    v += (int)__builtin_amdgcn_update_dpp(0u, (unsigned)v, 0x141, 0xF, 0xF, false);
+    v += (int)__builtin_amdgcn_update_dpp(0u, (unsigned)v, 0x140, 0xF, 0xF, false);
+    { const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false); v = (int)(r[0] + r[1]); }
+    { const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false); v = (int)(r[0] + r[1]); }
     return v;
 }
 // Binary-counter merge of aligned power-of-two chunks: returns the merged value so far;
@@ -73,7 +104,7 @@ __device__ __forceinline__ double stack_push(double (&stk)[LV], double t, int m)
 }
 
 // ----------------------------------------------------------------------------------------
-// k_sweep_simple (variant 0, straightforward reference form kept for A/B and cross-checks):
+// k_sweep_simple (variant 0, straightforward form kept for A/B and cross-checks):
 // one block = one owned plane x SWEEP_TJ rows.  The 14-neighbour state stencil is
 // staged in LDS (5 planes x (TJ+4) rows of the padded u8 state array, 16-B loads); T is
 // streamed once, 16 B per lane; theta/phi/defects/T-neighbours are gathered only at
@@ -159,255 +190,34 @@ __global__ __launch_bounds__(256) void k_sweep_simple(KParams P, SlabView S, con
 }
 
 // ----------------------------------------------------------------------------------------
-// k_sweep (variant 1): same tiling, but the rare transcendental-heavy events (attachment,
-// diffusion: only at occupied/empty interfaces) are NOT evaluated by the lane that owns the
-// voxel.  Phase A evaluates the cheap per-voxel part (deposition, nucleation, neighbour census)
-// for 2 voxels per lane; every interface event becomes a 4-byte work item in an LDS queue;
-// phase B spreads the items over consecutive lanes (full waves instead of 1-2 busy lanes);
-// phase C lets each owner add its items' rates in slot order, so the voxel sums -- and hence
-// the canonical tree -- are bit-identical to the simple form.
-// ----------------------------------------------------------------------------------------
-constexpr int SWEEP_Q = 2048;   // item queue capacity per round
-
-__device__ __forceinline__ double sweep_item_rate(const KParams& P, const SlabView& S, const unsigned char* smem,
-                                                  int li, int j0, unsigned desc)
-{
-    constexpr int TR = SWEEP_TJ + 4;
-    const int r = desc & 7, k = (desc >> 3) & 1023, m = (desc >> 13) & 15, n_bonds = (desc >> 17) & 15;
-    const int j = j0 + r;
-    const int di = nbi_rt(m), dj = nbj_rt(m), dk = nbk_rt(m);
-    const int st = smem[(int64_t)(2 * TR + r + 2) * S.pitchS + KOFF + k];
-    const double Tc = pymax(S.T[S.tidx(li, j, k)], 1.0);
-    double rate;
-    if (st == 0) {
-        const int sn = smem[(int64_t)((di + 2) * TR + (r + 2 + dj)) * S.pitchS + KOFF + k + dk];
-        rate = att_rate(P, S, li, j, k, di, dj, dk, sn, Tc);
-    } else {
-        rate = diff_rate(P, S, li, j, k, di, dj, dk, st, n_bonds, Tc);
-    }
-    return (rate > P.rate_threshold && finite_d(rate)) ? rate : -1.0;
-}
-
-__global__ __launch_bounds__(256) void k_sweep(KParams P, SlabView S, const double* __restrict__ ktab_g,
-                                               const StepState* __restrict__ ss)
-{
-    if (ss && ss->status) return;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int TJ = SWEEP_TJ, TR = TJ + 4;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int njt = (S.L + TJ - 1) / TJ;
-    const int nblk = S.nloc * njt;
-    int b = blockIdx.x;
-    if ((nblk & 7) == 0) b = (b & 7) * (nblk >> 3) + (b >> 3);   // contiguous plane ranges per XCD
-    const int lp = b / njt, jt = b - lp * njt;
-    const int j0 = jt * TJ, li = lp + 2, i = S.gi0 + lp;
-    const int pitchS = S.pitchS;
-    const int tile_bytes = (5 * TR * pitchS + 15) & ~15;
-    double* ktab = reinterpret_cast<double*>(smem + tile_bytes);
-    double* qres = ktab + 226;                                       // [SWEEP_Q]
-    unsigned* qdesc = reinterpret_cast<unsigned*>(qres + SWEEP_Q);   // [SWEEP_Q]
-    int* wave_tot = reinterpret_cast<int*>(qdesc + SWEEP_Q);         // [4]
-
-    {
-        const int cpr = pitchS >> 4;
-        const int nchunk = 5 * TR * cpr;
-        for (int idx = tid; idx < nchunk; idx += 256) {
-            int row = idx / cpr, ch = idx - row * cpr;
-            int p = row / TR, rr = row - p * TR;
-            const uint4* src = reinterpret_cast<const uint4*>(S.state + ((int64_t)(li - 2 + p) * S.RJ + (j0 + rr)) * pitchS) + ch;
-            reinterpret_cast<uint4*>(smem + (int64_t)row * pitchS)[ch] = *src;
-        }
-        if (tid < 225) ktab[tid] = ktab_g[tid];
-    }
-    __syncthreads();
-
-    const bool top = (i == S.L - 1);
-    const int nch = S.Pk > 128 ? (S.Pk >> 7) : 1;
-    double stk0[2][4], stk1[2][4], stk2[2][4];
-    double row0[2] = {0.0, 0.0}, row1[2] = {0.0, 0.0}, row2[2] = {0.0, 0.0};
-    int c0[2] = {0, 0}, c1[2] = {0, 0}, c2[2] = {0, 0};
-#pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-        const int r = w + 4 * rr;
-        const int j = j0 + r;
-        const unsigned char* own_row = smem + (int64_t)(2 * TR + r + 2) * pitchS + KOFF;
-        for (int m = 0; m < nch; ++m) {
-            const int k0 = (m << 7) + 2 * lane;
-            // ---- phase A: cheap part of both voxels ------------------------------------------
-            double mainv[2] = {0.0, 0.0}, depv[2] = {0.0, 0.0};
-            unsigned info[2] = {0u, 0u};   // [0:13] item mask  [14:17] n_bonds  [18] main valid  [19] dep valid  [20:21] 1 diff / 2 empty
-            if (j < S.L && k0 < S.L) {
-                const double2 Tv = *reinterpret_cast<const double2*>(S.T + S.tidx(li, j, k0));
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int k = k0 + h;
-                    const int st = (k < S.L) ? own_row[k] : OOB;
-                    if (st < 128 && st != 4) {
-                        int n_nb = 0, n_imp = 0, n_occ = 0;
-                        unsigned m_src = 0, m_empty = 0;
-#pragma unroll
-                        for (int mm = 0; mm < 14; ++mm) {
-                            const int sm = smem[(int64_t)((nbi_rt(mm) + 2) * TR + (r + 2 + nbj_rt(mm))) * pitchS + KOFF + k + nbk_rt(mm)];
-                            n_nb += (sm != OOB);
-                            n_imp += (sm == 2 || sm == 3);
-                            n_occ += (sm != 0 && sm != OOB);
-                            if (sm >= 1 && sm <= 3) m_src |= 1u << mm;
-                            if (sm == 0) m_empty |= 1u << mm;
-                        }
-                        const double Tc = pymax(h ? Tv.y : Tv.x, 1.0);
-                        if (st == 0) {
-                            unsigned inf = m_src | (2u << 20);
-                            if (top) {
-                                const double rate = dep_rate(P, Tc);
-                                if (finite_d(rate)) { depv[h] = rate; inf |= 1u << 19; }
-                            }
-                            const double dT = P.T_melt - Tc;
-                            if (dT > P.delta_T_c) {
-                                const double rate = nuc_rate(P, ktab[n_nb * 15 + n_imp], dT, P.kT * Tc);
-                                if (rate > P.rate_threshold && finite_d(rate)) { mainv[h] = rate; inf |= 1u << 18; }
-                            }
-                            info[h] = inf;
-                        } else {
-                            info[h] = m_empty | ((unsigned)n_occ << 14) | (1u << 20);
-                        }
-                    }
-                }
-            }
-            // ---- phase B: interface events through the block-wide item queue ----------------------
-            const int n0 = __builtin_popcount(info[0] & 0x3FFF), n1 = __builtin_popcount(info[1] & 0x3FFF);
-            int cnt[2] = {(int)((info[0] >> 18) & 1), (int)((info[1] >> 18) & 1)};
-            if (__syncthreads_or(n0 + n1)) {
-                int incl = n0 + n1;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-                if (lane == 63) wave_tot[w] = incl;
-                __syncthreads();
-                int base = incl - (n0 + n1), total = 0;
-#pragma unroll
-                for (int ww = 0; ww < 4; ++ww) { const int t = wave_tot[ww]; if (ww < w) base += t; total += t; }
-                const int nrounds = (total + SWEEP_Q - 1) / SWEEP_Q;
-                for (int rho = 0; rho < nrounds; ++rho) {
-                    if (rho) __syncthreads();
-                    int g = base;
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        unsigned mk = info[h] & 0x3FFF;
-                        while (mk) {
-                            const int mm = __builtin_ctz(mk);
-                            mk &= mk - 1;
-                            if (g / SWEEP_Q == rho)
-                                qdesc[g % SWEEP_Q] = (unsigned)r | ((unsigned)(k0 + h) << 3) | ((unsigned)mm << 13) | (((info[h] >> 14) & 15u) << 17);
-                            ++g;
-                        }
-                    }
-                    __syncthreads();
-                    const int nq = min(SWEEP_Q, total - rho * SWEEP_Q);
-                    for (int q = tid; q < nq; q += 256) qres[q] = sweep_item_rate(P, S, smem, li, j0, qdesc[q]);
-                    __syncthreads();
-                    g = base;
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        unsigned mk = info[h] & 0x3FFF;
-                        while (mk) {
-                            mk &= mk - 1;
-                            if (g / SWEEP_Q == rho) {
-                                const double rt = qres[g % SWEEP_Q];
-                                if (rt >= 0.0) { mainv[h] = mainv[h] + rt; ++cnt[h]; }
-                            }
-                            ++g;
-                        }
-                    }
-                }
-            }
-            // ---- phase C: canonical reduction (pair, wave butterfly, chunk merge) ------------------
-            const int kind0 = (info[0] >> 20) & 3, kind1 = (info[1] >> 20) & 3;
-            double s1 = (kind0 == 1 ? mainv[0] : 0.0) + (kind1 == 1 ? mainv[1] : 0.0);
-            double s2 = (kind0 == 2 ? mainv[0] : 0.0) + (kind1 == 2 ? mainv[1] : 0.0);
-            double s0 = depv[0] + depv[1];
-            int cpack = (int)((info[0] >> 19) & 1) + (int)((info[1] >> 19) & 1)
-                      + (((kind0 == 1 ? cnt[0] : 0) + (kind1 == 1 ? cnt[1] : 0)) << 8)
-                      + (((kind0 == 2 ? cnt[0] : 0) + (kind1 == 2 ? cnt[1] : 0)) << 19);
-            if (top) s0 = wave_tree_sum(s0);
-            s1 = wave_tree_sum(s1);
-            s2 = wave_tree_sum(s2);
-            cpack = wave_sum_i(cpack);
-            c0[rr] += cpack & 0xFF; c1[rr] += (cpack >> 8) & 0x7FF; c2[rr] += (cpack >> 19) & 0x7FF;
-            row0[rr] = stack_push(stk0[rr], s0, m);
-            row1[rr] = stack_push(stk1[rr], s1, m);
-            row2[rr] = stack_push(stk2[rr], s2, m);
-        }
-        if (lane == 0 && j < S.L) {
-            const int64_t o = (int64_t)lp * 3 * S.L + j;
-            S.rowsum[o] = row0[rr]; S.rowsum[o + S.L] = row1[rr]; S.rowsum[o + 2 * S.L] = row2[rr];
-            S.rowcnt[o] = c0[rr]; S.rowcnt[o + S.L] = c1[rr]; S.rowcnt[o + 2 * S.L] = c2[rr];
-        }
-    }
-}
-
-// ----------------------------------------------------------------------------------------
-// k_sweep_march (variant 2, default): 2.5-D blocking.  One block owns SWEEP_TJ rows and
-// marches over MARCH_NI consecutive planes, keeping a 5-plane ring of the u16 census-class
-// array in LDS (each class word is fetched ~1.5x instead of 7.5x).  A lane handles 4
+// k_sweep_stream (variant 1, default): 2.5-D blocking.  One block owns SWEEP_TJ rows and
+// marches over STREAM_NI consecutive planes, keeping a 5-plane ring of the u16 census-class
+// array in LDS (each class word is fetched ~1.9x instead of 7.5x).  A lane handles 4
 // consecutive voxels of a row: the 14-neighbour census (#in-bounds, #empty, #W/Re/C, #Re/C)
 // of all 4 voxels is 17 LDS loads + SWAR adds on packed 4-bit counters -- no compares.
-// T is streamed once (32 B per lane).  Interface events (attachment/diffusion) go through
-// the block-wide item queue as in variant 1; voxel sums are accumulated in slot order, so
-// row sums are bit-identical to the simple kernel and to the oracle's canonical tree.
+// T is streamed once (32 B per lane).  Interface voxels (census says: empty with a W/Re/C
+// neighbour, or atom with an empty neighbour) take their category sum from ifc_val/ifc_cnt,
+// which k_interface filled in this step; all other empty voxels get their nucleation rate
+// here.  Row sums follow the canonical tree: 4-voxel tree, wave butterfly, chunk tree.
 // ----------------------------------------------------------------------------------------
-constexpr int MARCH_NI = 8;     // planes per block
-constexpr int MARCH_Q = 1024;   // item-queue capacity per round
-constexpr int MARCH_MAXCH = 4;  // chunks of 256 voxels per row (L <= 1024)
+constexpr int STREAM_NI = 8;      // planes per block
+constexpr int STREAM_MAXCH = 4;   // chunks of 256 voxels per row (L <= 1024)
 
-// Everything the hot part of k_sweep_march needs, by value (stays in SGPRs); the rare
-// interface-event path reads the full KParams/SlabView through pointers instead.
-struct MarchArgs {
+struct StreamArgs {
     double T_melt, delta_T_c, kT, I0, rate_threshold, nu_dep;
-    int L, gi0, nloc, RJ, pitchC, pitchT, Pk;
+    int L, gi0, nloc, RJ, pitchC, pitchT, Pk, group_first, group_count;
     const uint16_t* cls;
     const double* T;
+    const double* ifc_val;
+    const uint8_t* ifc_cnt;
     double* rowsum;
     int32_t* rowcnt;
 };
 
-__device__ __noinline__ double march_item_rate(const KParams* __restrict__ Pg, const SlabView* __restrict__ Sg,
-                                               int li, int j0, unsigned desc)
-{
-    const KParams P = *Pg;
-    const SlabView S = *Sg;
-    const int r = desc & 7, k = (desc >> 3) & 1023, m = (desc >> 13) & 15, n_bonds = (desc >> 17) & 15;
-    const int j = j0 + r;
-    const int di = nbi_rt(m), dj = nbj_rt(m), dk = nbk_rt(m);
-    const int st = S.state[S.sidx(li, j, k)];
-    const double Tc = pymax(S.T[S.tidx(li, j, k)], 1.0);
-    double rate;
-    if (st == 0) rate = att_rate(P, S, li, j, k, di, dj, dk, S.state[S.sidx(li + di, j + dj, k + dk)], Tc);
-    else rate = diff_rate(P, S, li, j, k, di, dj, dk, st, n_bonds, Tc);
-    return (rate > P.rate_threshold && finite_d(rate)) ? rate : -1.0;
-}
-
-// item descriptors of one voxel (rare path): which neighbour slots are sources / free sites
-__device__ __noinline__ int march_push_items(const SlabView* __restrict__ Sg, unsigned* qdesc, int li, int j, int r, int k,
-                                             bool want_src, unsigned n_bonds, int g, int rho)
-{
-    const SlabView S = *Sg;
-#pragma unroll 1
-    for (int mm = 0; mm < 14; ++mm) {
-        const int sm = S.state[S.sidx(li + nbi_rt(mm), j + nbj_rt(mm), k + nbk_rt(mm))];
-        const bool hit = want_src ? (sm >= 1 && sm <= 3) : (sm == 0);
-        if (hit) {
-            if (g / MARCH_Q == rho)
-                qdesc[g % MARCH_Q] = (unsigned)r | ((unsigned)k << 3) | ((unsigned)mm << 13) | (n_bonds << 17);
-            ++g;
-        }
-    }
-    return g;
-}
-
 __device__ __forceinline__ unsigned alignbit16(unsigned hi, unsigned lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
 
-__global__ __launch_bounds__(256) void k_sweep_march(MarchArgs A, const KParams* __restrict__ Pg,
-                                                     const SlabView* __restrict__ Sg, const double* __restrict__ ktab_g,
-                                                     const StepState* __restrict__ ss)
+__global__ __launch_bounds__(256) void k_sweep_stream(StreamArgs A, const double* __restrict__ ktab_g,
+                                                      const StepState* __restrict__ ss)
 {
     if (ss && ss->status) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -415,22 +225,18 @@ __global__ __launch_bounds__(256) void k_sweep_march(MarchArgs A, const KParams*
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int L = A.L;
     const int njt = (L + TJ - 1) / TJ;
-    const int nib = (A.nloc + MARCH_NI - 1) / MARCH_NI;
-    const int nblk = njt * nib;
+    const int nblk = njt * A.group_count;
     int b = blockIdx.x;
     if ((nblk & 7) == 0) b = (b & 7) * (nblk >> 3) + (b >> 3);   // contiguous block ranges per XCD
-    const int ib = b / njt, jt = b - ib * njt;
+    const int ibr = b / njt, jt = b - ibr * njt;
     const int j0 = jt * TJ;
-    const int lp0 = ib * MARCH_NI, lp1 = min(lp0 + MARCH_NI, A.nloc);
+    const int lp0 = (A.group_first + ibr) * STREAM_NI, lp1 = min(lp0 + STREAM_NI, A.nloc);
     const int pitchC = A.pitchC;
     const int slab = TR * pitchC;                                     // u16 per plane slab
     uint16_t* ring = reinterpret_cast<uint16_t*>(smem);
     const int ring_bytes = (5 * slab * 2 + 15) & ~15;
     double* ktab = reinterpret_cast<double*>(smem + ring_bytes);      // [226]
-    double* qres = ktab + 226;                                        // [MARCH_Q]
-    double* rowpart = qres + MARCH_Q;                                 // [TJ][3][MARCH_MAXCH]
-    unsigned* qdesc = reinterpret_cast<unsigned*>(rowpart + TJ * 3 * MARCH_MAXCH);   // [MARCH_Q]
-    int* wave_tot = reinterpret_cast<int*>(qdesc + MARCH_Q);          // [4]
+    double* rowpart = ktab + 226;                                     // [TJ][3][STREAM_MAXCH]
 
     const int cpr = pitchC >> 3;                                      // 16-B chunks per class row
     auto load_slab = [&](int lsrc) {
@@ -444,8 +250,8 @@ __global__ __launch_bounds__(256) void k_sweep_march(MarchArgs A, const KParams*
     const int nch = A.Pk > 256 ? (A.Pk >> 8) : 1;
 #pragma unroll 1
     for (int lp = lp0; lp < lp1; ++lp) {
-        const int li = lp + 2, i = A.gi0 + lp;
-        const bool top = (i == L - 1);
+        const int li = lp + 2;
+        const bool top = (A.gi0 + lp == L - 1);
         load_slab(li + 2);
         __syncthreads();
         int so[5];
@@ -458,14 +264,11 @@ __global__ __launch_bounds__(256) void k_sweep_march(MarchArgs A, const KParams*
 #pragma unroll 1
             for (int m = 0; m < nch; ++m) {
                 const int k0 = (m << 8) + 4 * lane;
-                double mainv[4] = {0.0, 0.0, 0.0, 0.0};
-                unsigned info[4] = {0u, 0u, 0u, 0u};   // [1:0] kind 1 diff / 2 empty, [2] main valid, [6:3] #items, [10:7] n_bonds
-                double deps = 0.0;
-                int nitems = 0;
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0;     // 4-voxel trees (v0+v1)+(v2+v3), built pair by pair
                 if (j < L && k0 < L) {
-                    const double2 Ta = *reinterpret_cast<const double2*>(A.T + ((int64_t)li * L + j) * A.pitchT + k0);
-                    const double2 Tb = (k0 + 2 < L) ? *reinterpret_cast<const double2*>(A.T + ((int64_t)li * L + j) * A.pitchT + k0 + 2)
-                                                    : make_double2(0.0, 0.0);
+                    const int64_t trow = ((int64_t)li * L + j) * A.pitchT + k0;
+                    const double2 Ta = *reinterpret_cast<const double2*>(A.T + trow);
+                    const double2 Tb = (k0 + 2 < L) ? *reinterpret_cast<const double2*>(A.T + trow + 2) : make_double2(0.0, 0.0);
                     // ---- SWAR census of the 4 voxels' 14 neighbours ------------------------------
                     auto rowp = [&](int d, int row) { return ring + so[d + 2] + row * pitchC + KOFFC + k0; };
                     auto ld2 = [&](const uint16_t* p) { return *reinterpret_cast<const uint2*>(p); };
@@ -491,101 +294,50 @@ __global__ __launch_bounds__(256) void k_sweep_march(MarchArgs A, const KParams*
                     const unsigned Aw = ld1(po - 2), Cw = ld1(po + 4);
                     const uint2 own = ld2(po);
                     acc.x += Aw + own.y; acc.y += own.x + Cw;
-                    // ---- cheap per-voxel part ----------------------------------------------------
-                    double dsum[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
+                    // ---- per-voxel part (one voxel at a time: keeps the register footprint small) ----
+                    double p0 = 0.0, p1 = 0.0, p2 = 0.0;             // even voxel of the current pair
+#pragma unroll 2
                     for (int h = 0; h < 4; ++h) {
-                        const unsigned f = ((h < 2 ? acc.x : acc.y) >> (16 * (h & 1))) & 0xFFFFu;
-                        const unsigned oc = ((h < 2 ? own.x : own.y) >> (16 * (h & 1))) & 0xFFFFu;
-                        const int n_nb = f & 15, n_empty = (f >> 4) & 15, n_src = (f >> 8) & 15, n_imp = (f >> 12) & 15;
-                        if (oc & 0x10u) {                            // empty voxel
-                            const double Tc = pymax(h == 0 ? Ta.x : h == 1 ? Ta.y : h == 2 ? Tb.x : Tb.y, 1.0);
-                            unsigned inf = 2u | ((unsigned)n_src << 3);
+                        const int sh = 16 * (h & 1);
+                        const unsigned f = ((h < 2 ? acc.x : acc.y) >> sh) & 0xFFFFu;
+                        const unsigned oc = ((h < 2 ? own.x : own.y) >> sh) & 0xFFFFu;
+                        const bool empty = (oc & 0x10u) != 0;
+                        double ev = 0.0, dv = 0.0, depv = 0.0;
+                        if (empty) {
+                            const double Traw = (h < 2) ? (h == 0 ? Ta.x : Ta.y) : (h == 2 ? Tb.x : Tb.y);
+                            const double Tc = pymax(Traw, 1.0);
                             if (top) {
                                 const double rate = A.nu_dep * exp(-(A.T_melt - Tc) / (A.kT * Tc));
-                                if (finite_d(rate)) { dsum[h] = rate; ++cdep; }
+                                if (finite_d(rate)) { depv = rate; ++cdep; }
                             }
-                            const double dT = A.T_melt - Tc;
-                            if (dT > A.delta_T_c) {
-                                const double aa = dT + 1e-6;
-                                const double barrier = ktab[n_nb * 15 + n_imp] / pymax(aa * aa, 1e-6);
-                                const double rate = A.I0 * exp(-barrier / (A.kT * Tc));
-                                if (rate > A.rate_threshold && finite_d(rate)) { mainv[h] = rate; inf |= 4u; }
-                            }
-                            info[h] = inf;
-                            nitems += n_src;
-                        } else if (oc & 0x100u) {                    // W / Re / C atom
-                            info[h] = 1u | ((unsigned)n_empty << 3) | ((unsigned)(n_nb - n_empty) << 7);
-                            nitems += n_empty;
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    deps = (dsum[0] + dsum[1]) + (dsum[2] + dsum[3]);
-                }
-                // ---- interface events through the block-wide item queue ----------------------------
-                int cnt[4];
-#pragma unroll
-                for (int h = 0; h < 4; ++h) cnt[h] = (info[h] >> 2) & 1;
-                if (__syncthreads_or(nitems)) {
-                    int incl = nitems;
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-                    if (lane == 63) wave_tot[w] = incl;
-                    __syncthreads();
-                    int base = incl - nitems, total = 0;
-#pragma unroll
-                    for (int ww = 0; ww < 4; ++ww) { const int t = wave_tot[ww]; if (ww < w) base += t; total += t; }
-                    const int nrounds = (total + MARCH_Q - 1) / MARCH_Q;
-#pragma unroll 1
-                    for (int rho = 0; rho < nrounds; ++rho) {
-                        if (rho) __syncthreads();
-                        if (nitems) {
-                            int g = base;
-#pragma unroll
-                            for (int h = 0; h < 4; ++h)
-                                if ((info[h] >> 3) & 15u)
-                                    g = march_push_items(Sg, qdesc, li, j, r, k0 + h, (info[h] & 3u) == 2u, (info[h] >> 7) & 15u, g, rho);
-                        }
-                        __syncthreads();
-                        const int nq = min(MARCH_Q, total - rho * MARCH_Q);
-#pragma unroll 1
-                        for (int q = tid; q < nq; q += 256) qres[q] = march_item_rate(Pg, Sg, li, j0, qdesc[q]);
-                        __syncthreads();
-                        if (nitems) {
-                            int g = base;
-#pragma unroll
-                            for (int h = 0; h < 4; ++h) {
-                                const int ni = (info[h] >> 3) & 15;
-                                for (int t = 0; t < ni; ++t, ++g) {
-                                    if (g / MARCH_Q == rho) {
-                                        const double rt = qres[g % MARCH_Q];
-                                        if (rt >= 0.0) { mainv[h] = mainv[h] + rt; ++cnt[h]; }
-                                    }
+                            if (f & 0x0F00u) {                       // has W/Re/C neighbours: interface voxel
+                                ev = A.ifc_val[trow + h];
+                                cemp += A.ifc_cnt[trow + h];
+                            } else {
+                                const double dT = A.T_melt - Tc;
+                                if (dT > A.delta_T_c) {
+                                    const int n_nb = f & 15, n_imp = (f >> 12) & 15;
+                                    const double rate = nuc_rate_s(A.I0, ktab[n_nb * 15 + n_imp], dT, A.kT * Tc);
+                                    if (rate > A.rate_threshold && finite_d(rate)) { ev = rate; ++cemp; }
                                 }
                             }
+                        } else if ((oc & 0x100u) && (f & 0x00F0u)) { // atom with empty neighbours
+                            dv = A.ifc_val[trow + h];
+                            cdiff += A.ifc_cnt[trow + h];
                         }
+                        if (!(h & 1)) { p0 = depv; p1 = dv; p2 = ev; }
+                        else if (h == 1) { s0 = p0 + depv; s1 = p1 + dv; s2 = p2 + ev; }
+                        else { s0 = s0 + (p0 + depv); s1 = s1 + (p1 + dv); s2 = s2 + (p2 + ev); }
                     }
                 }
-                // ---- canonical reduction: 4-voxel tree, wave butterfly, chunk partial to LDS --------
-                double e[4], d[4];
-#pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    const unsigned kind = info[h] & 3u;
-                    e[h] = (kind == 2u) ? mainv[h] : 0.0;
-                    d[h] = (kind == 1u) ? mainv[h] : 0.0;
-                    cemp += (kind == 2u) ? cnt[h] : 0;
-                    cdiff += (kind == 1u) ? cnt[h] : 0;
-                }
-                double s2 = (e[0] + e[1]) + (e[2] + e[3]);
-                double s1 = (d[0] + d[1]) + (d[2] + d[3]);
-                double s0 = deps;
+                // ---- wave butterfly, chunk partial to LDS ---------------------------------------------
                 if (__any(s2 != 0.0)) s2 = wave_tree_sum(s2);
                 if (__any(s1 != 0.0)) s1 = wave_tree_sum(s1);
                 if (top && __any(s0 != 0.0)) s0 = wave_tree_sum(s0);
                 if (lane == 0) {
-                    rowpart[(r * 3 + 0) * MARCH_MAXCH + m] = s0;
-                    rowpart[(r * 3 + 1) * MARCH_MAXCH + m] = s1;
-                    rowpart[(r * 3 + 2) * MARCH_MAXCH + m] = s2;
+                    rowpart[(r * 3 + 0) * STREAM_MAXCH + m] = s0;
+                    rowpart[(r * 3 + 1) * STREAM_MAXCH + m] = s1;
+                    rowpart[(r * 3 + 2) * STREAM_MAXCH + m] = s2;
                 }
             }
             // ---- row totals: balanced tree over the chunk partials; counts reduced once ------------
@@ -594,7 +346,7 @@ __global__ __launch_bounds__(256) void k_sweep_march(MarchArgs A, const KParams*
                 const int64_t o = (int64_t)lp * 3 * L + j;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    double* p = rowpart + (r * 3 + c) * MARCH_MAXCH;
+                    double* p = rowpart + (r * 3 + c) * STREAM_MAXCH;
                     for (int n = nch; n > 1; n >>= 1)
                         for (int t = 0; t < (n >> 1); ++t) p[t] = p[2 * t] + p[2 * t + 1];
                     A.rowsum[o + (int64_t)c * L] = p[0];
@@ -783,6 +535,82 @@ __global__ __launch_bounds__(256) void k_select(KParams P, const SlabView* __res
     }
 }
 
+// ---- interface voxels --------------------------------------------------------------------
+// A voxel "owns interface events" iff it is empty with a W/Re/C neighbour (attachment) or a
+// W/Re/C atom with an empty neighbour (diffusion).  These are rare (a few per lattice row) and
+// expensive, so they are kept in a per-slab list (append-only superset, rebuilt at upload),
+// evaluated one voxel per lane by k_interface into ifc_val/ifc_cnt every step, and merely
+// looked up by the streaming sweep kernel.
+__device__ __forceinline__ bool is_interface(const SlabView& S, int li, int j, int k)
+{
+    const int st = S.state[S.sidx(li, j, k)];
+    if (st >= 128 || st == 4) return false;
+    bool hit = false;
+#pragma unroll 1
+    for (int m = 0; m < 14; ++m) {
+        const int sm = S.state[S.sidx(li + nbi_rt(m), j + nbj_rt(m), k + nbk_rt(m))];
+        hit |= (st == 0) ? (sm >= 1 && sm <= 3) : (sm == 0);
+    }
+    return hit;
+}
+__device__ __forceinline__ void ifc_append(const SlabView& S, int lp, int j, int k)
+{
+    const int64_t t = S.tidx(lp + 2, j, k);
+    if (S.ifc_in[t]) return;
+    S.ifc_in[t] = 1;
+    const int pos = atomicAdd(S.ifc_n, 1);
+    S.ifc_list[pos] = ((unsigned)lp << 20) | ((unsigned)j << 10) | (unsigned)k;
+}
+// full rebuild (upload): grid-stride over the owned voxels
+__global__ void k_ifc_rebuild(SlabView S)
+{
+    const int L = S.L;
+    const int64_t n = (int64_t)S.nloc * L * L;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % L);
+        const int64_t t = idx / L;
+        const int j = (int)(t % L), lp = (int)(t / L);
+        if (is_interface(S, lp + 2, j, k)) ifc_append(S, lp, j, k);
+    }
+}
+// after an event changed voxel (i,j,k): it and its 14 neighbours may have become interface
+// voxels.  Called by a full wave: lane l < 15 checks one of them.
+__device__ __forceinline__ void ifc_touch(const SlabView& S, int i, int j, int k, int lane)
+{
+    if (lane >= 15) return;
+    int ai = i, aj = j, ak = k;
+    if (lane < 14) { ai += nbi_rt(lane); aj += nbj_rt(lane); ak += nbk_rt(lane); }
+    const int L = S.L;
+    if (ai < 0 || ai >= L || aj < 0 || aj >= L || ak < 0 || ak >= L) return;
+    const int lp = ai - S.gi0;
+    if (lp < 0 || lp >= S.nloc) return;                      // owned planes only
+    if (is_interface(S, lp + 2, aj, ak)) ifc_append(S, lp, aj, ak);
+}
+// every step: EMPTY/DIFF category sum + count of every listed voxel, one voxel per lane
+__global__ __launch_bounds__(256) void k_interface(KParams P, SlabView S, const double* __restrict__ ktab_g,
+                                                   const StepState* __restrict__ ss)
+{
+    if (ss && ss->status) return;
+    __shared__ double ktab[225];
+    if (threadIdx.x < 225) ktab[threadIdx.x] = ktab_g[threadIdx.x];
+    __syncthreads();
+    const int n = *S.ifc_n;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+        const unsigned v = S.ifc_list[q];
+        const int lp = v >> 20, j = (v >> 10) & 1023, k = v & 1023;
+        const int li = lp + 2, i = S.gi0 + lp;
+        const int st = S.state[S.sidx(li, j, k)];
+        double sum = 0.0;
+        int cnt = 0;
+        auto nb = [&](int mm) -> int { return S.state[S.sidx(li + nbi_rt(mm), j + nbj_rt(mm), k + nbk_rt(mm))]; };
+        auto emit = [&](int cat, int, double rate, int, int) { if (cat != CAT_DEP) { sum += rate; ++cnt; } };
+        eval_voxel(P, S, ktab, li, i, j, k, st, S.T[S.tidx(li, j, k)], nb, emit);
+        const int64_t t = S.tidx(li, j, k);
+        S.ifc_val[t] = sum;
+        S.ifc_cnt[t] = (uint8_t)cnt;
+    }
+}
+
 // ---- apply -------------------------------------------------------------------------------
 __device__ __forceinline__ void write_site(const SlabView& S, int i, int j, int k, int st, double th, double ph)
 {
@@ -798,7 +626,7 @@ __device__ __forceinline__ void write_site(const SlabView& S, int i, int j, int 
 __device__ __forceinline__ void apply_event(const SlabView* slabs, int nslabs, const cetkmc_event& ev, int make_defect)
 {
     for (int s = 0; s < nslabs; ++s) {
-        const SlabView S = slabs[s];
+        const SlabView& S = slabs[s];
         int ui = ev.pos[0], uj = ev.pos[1], uk = ev.pos[2];
         if (ev.type == EV_DEP || ev.type == EV_NUC || ev.type == EV_ATT) {
             write_site(S, ui, uj, uk, ev.atom, ev.theta, ev.phi);
@@ -808,6 +636,16 @@ __device__ __forceinline__ void apply_event(const SlabView* slabs, int nslabs, c
             ui = ev.target[0]; uj = ev.target[1]; uk = ev.target[2];   // :303
         }
         if (make_defect) write_site(S, ui, uj, uk, 4, 0.0, 0.0);       // :323-327
+    }
+}
+
+// interface-list update for the voxels an event touched (all lanes of the first wave)
+__device__ __forceinline__ void apply_touch(const SlabView* slabs, int nslabs, const cetkmc_event& ev, int lane)
+{
+    for (int s = 0; s < nslabs; ++s) {
+        const SlabView& S = slabs[s];
+        ifc_touch(S, ev.pos[0], ev.pos[1], ev.pos[2], lane);
+        if (ev.type == EV_DIFF) ifc_touch(S, ev.target[0], ev.target[1], ev.target[2], lane);
     }
 }
 
@@ -832,49 +670,66 @@ __device__ __forceinline__ int dep_species(const KParams& P, double u)
     return 1;
 }
 
-// Batched apply: RNG bookkeeping of one step + lattice update + per-step logs.
-__global__ void k_apply_batch(KParams P, const SlabView* __restrict__ slabs, int nslabs, int L,
-                              const cetkmc_event* __restrict__ events_all, int G, StepState* ss, BatchCfg cfg,
-                              const double* __restrict__ u_defect, const double* __restrict__ u_np,
-                              double* log_total, cetkmc_event* log_event, int64_t* log_nev)
+// Batched apply: RNG bookkeeping of one step + lattice update + per-step logs (lane 0), then the
+// interface-list update for the touched voxels (whole wave).  Launched with ONE 64-thread block.
+__global__ __launch_bounds__(64) void k_apply_batch(KParams P, const SlabView* __restrict__ slabs, int nslabs, int L,
+                                                    const cetkmc_event* __restrict__ events_all, int G, StepState* ss,
+                                                    BatchCfg cfg, const double* __restrict__ u_defect,
+                                                    const double* __restrict__ u_np, double* log_total,
+                                                    cetkmc_event* log_event, int64_t* log_nev)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (ss->status) return;
-    cetkmc_event ev;
-    ev.type = -1;
-    for (int g = 0; g < G; ++g) if (events_all[g].type >= 0) ev = events_all[g];
-    const int64_t s = ss->cur;
-    if (ev.type < 0) { ss->status = 1; return; }
-    int64_t pos = ss->np_pos;
-    if (ev.type == EV_DEP) {
-        const double u = (cfg.rng_mode == 0)
-            ? u_np[pos + ev.dep_rank]
-            : counter_uniform(cfg.seed, (uint64_t)(cfg.step0 + s), (uint64_t)ev.pos[1] * (uint64_t)L + (uint64_t)ev.pos[2]);
-        ev.atom = dep_species(P, u);
+    __shared__ cetkmc_event sh_ev;
+    __shared__ int sh_ok;
+    if (threadIdx.x == 0) {
+        sh_ok = 0;
+        if (!ss->status) {
+            cetkmc_event ev;
+            ev.type = -1;
+            for (int g = 0; g < G; ++g) if (events_all[g].type >= 0) ev = events_all[g];
+            const int64_t s = ss->cur;
+            if (ev.type < 0) {
+                ss->status = 1;
+            } else {
+                int64_t pos = ss->np_pos;
+                if (ev.type == EV_DEP) {
+                    const double u = (cfg.rng_mode == 0)
+                        ? u_np[pos + ev.dep_rank]
+                        : counter_uniform(cfg.seed, (uint64_t)(cfg.step0 + s), (uint64_t)ev.pos[1] * (uint64_t)L + (uint64_t)ev.pos[2]);
+                    ev.atom = dep_species(P, u);
+                }
+                if (cfg.rng_mode == 0) pos += ss->n_dep;
+                if (ev.type == EV_DEP || ev.type == EV_NUC) {
+                    ev.theta = 0.0 + (3.141592653589793 - 0.0) * u_np[pos];       // np.random.uniform(0, pi)
+                    ev.phi = 0.0 + (6.283185307179586 - 0.0) * u_np[pos + 1];     // np.random.uniform(0, 2*pi)
+                    pos += 2;
+                    if (ev.type == EV_NUC) ss->nuc_count += 1;
+                }
+                const int mk = (cfg.defect_fraction > 0.0 && u_defect[s] < cfg.defect_fraction) ? 1 : 0;
+                apply_event(slabs, nslabs, ev, mk);
+                ss->np_pos = pos;
+                if (log_total) log_total[s] = ss->total;
+                if (log_event) log_event[s] = ev;
+                if (log_nev) log_nev[s] = ss->n_events;
+                ss->cur = s + 1;
+                sh_ev = ev;
+                sh_ok = 1;
+            }
+        }
     }
-    if (cfg.rng_mode == 0) pos += ss->n_dep;
-    if (ev.type == EV_DEP || ev.type == EV_NUC) {
-        ev.theta = 0.0 + (3.141592653589793 - 0.0) * u_np[pos];       // np.random.uniform(0, pi)
-        ev.phi = 0.0 + (6.283185307179586 - 0.0) * u_np[pos + 1];     // np.random.uniform(0, 2*pi)
-        pos += 2;
-        if (ev.type == EV_NUC) ss->nuc_count += 1;
-    }
-    const int mk = (cfg.defect_fraction > 0.0 && u_defect[s] < cfg.defect_fraction) ? 1 : 0;
-    apply_event(slabs, nslabs, ev, mk);
-    ss->np_pos = pos;
-    if (log_total) log_total[s] = ss->total;
-    if (log_event) log_event[s] = ev;
-    if (log_nev) log_nev[s] = ss->n_events;
-    ss->cur = s + 1;
+    __syncthreads();
+    if (sh_ok) apply_touch(slabs, nslabs, sh_ev, threadIdx.x);
 }
 
-// Direct apply (cetkmc_apply): everything decided by the host.
-__global__ void k_apply_direct(const SlabView* __restrict__ slabs, int nslabs, cetkmc_event ev, int make_defect,
-                               StepState* ss)
+// Direct apply (cetkmc_apply): everything decided by the host.  ONE 64-thread block.
+__global__ __launch_bounds__(64) void k_apply_direct(const SlabView* __restrict__ slabs, int nslabs, cetkmc_event ev,
+                                                     int make_defect, StepState* ss)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (ev.type == EV_NUC) ss->nuc_count += 1;
-    apply_event(slabs, nslabs, ev, make_defect);
+    if (threadIdx.x == 0) {
+        if (ev.type == EV_NUC) ss->nuc_count += 1;
+        apply_event(slabs, nslabs, ev, make_defect);
+    }
+    __syncthreads();
+    apply_touch(slabs, nslabs, ev, threadIdx.x);
 }
 
 // ---- thermal -------------------------------------------------------------------------------

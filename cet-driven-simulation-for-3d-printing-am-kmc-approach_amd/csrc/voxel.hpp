@@ -63,6 +63,12 @@ struct SlabView {
     double* ovec;       // [(nloc+4)][L][pitchT][3] orientation unit vectors (sin t cos p, sin t sin p, cos t)
     double* rowsum;     // [nloc*3][L]  row sums of the last sweep, index (lp*3+cat)*L + j
     int32_t* rowcnt;
+    // interface voxels (voxels owning attachment / diffusion events), see k_interface:
+    double* ifc_val;    // [(nloc+4)][L][pitchT] EMPTY- or DIFF-category sum of an interface voxel (tidx)
+    uint8_t* ifc_cnt;   // same indexing: its event count
+    uint8_t* ifc_in;    // same indexing: 1 if the voxel is in ifc_list
+    uint32_t* ifc_list; // packed (lp << 20 | j << 10 | k) of the listed voxels (append-only, superset)
+    int* ifc_n;         // number of listed voxels
     __device__ __forceinline__ int64_t sidx(int li, int j, int k) const {
         return ((int64_t)li * RJ + (j + 2)) * pitchS + KOFF + k;
     }
@@ -120,12 +126,47 @@ __device__ __forceinline__ double dep_rate(const KParams& P, double Tc)
 {
     return P.nu_dep * exp(-(P.T_melt - Tc) / (P.kT * Tc));
 }
-// kmc_event_rates.py:126-130 with K_eff from the table
+// exp(x) for x <= 0 (NaN -> 0): round-to-nearest reduction x = n*ln2 + r, |r| <= ln2/2, degree-13
+// Taylor polynomial in Horner form (truncation 4e-18), scaled by 2^n.  About 1 ulp; no overflow path
+// (x <= 0) and underflow falls out of v_ldexp_f64.  Used for the nucleation rate, whose argument is
+// -barrier/(kT*T) <= 0 by construction.
+__device__ __forceinline__ double exp_nonpos(double x)
+{
+    x = fmax(x, -1000.0);
+    const double n = rint(x * 1.4426950408889634074);
+    double r = fma(n, -6.93147180369123816490e-01, x);
+    r = fma(n, -1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;                 // 1/13!
+    p = fma(p, r, 2.08767569878681e-09);               // 1/12!
+    p = fma(p, r, 2.505210838544172e-08);              // 1/11!
+    p = fma(p, r, 2.755731922398589e-07);              // 1/10!
+    p = fma(p, r, 2.7557319223985893e-06);             // 1/9!
+    p = fma(p, r, 2.48015873015873e-05);               // 1/8!
+    p = fma(p, r, 1.984126984126984e-04);              // 1/7!
+    p = fma(p, r, 1.388888888888889e-03);              // 1/6!
+    p = fma(p, r, 8.333333333333333e-03);              // 1/5!
+    p = fma(p, r, 4.1666666666666664e-02);             // 1/4!
+    p = fma(p, r, 1.6666666666666666e-01);             // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
+// kmc_event_rates.py:126-130 with K_eff from the table.  The reference's two divisions
+// barrier = K/den; x = -barrier/kTT are evaluated as ONE: x = -K/(den*kTT) (differs from the
+// reference's rounding by <= 2 ulp of x, i.e. <= ~1e-15 relative in the rate), and the
+// exponential by exp_nonpos().  Every kernel uses this one function, so GPU-side sums are
+// mutually bit-consistent.
+__device__ __forceinline__ double nuc_rate_s(double I0, double K, double dT, double kTT)
+{
+    const double a = dT + 1e-6;
+    const double den = pymax(a * a, 1e-6);
+    return I0 * exp_nonpos(-K / (den * kTT));
+}
 __device__ __forceinline__ double nuc_rate(const KParams& P, double K, double dT, double kTT)
 {
-    double a = dT + 1e-6;
-    double barrier = K / pymax(a * a, 1e-6);
-    return P.I0 * exp(-barrier / kTT);
+    return nuc_rate_s(P.I0, K, dT, kTT);
 }
 // kmc_event_rates.py:147-156: attachment of species sn from neighbour slot m to empty voxel (li,j,k).
 // The orientation unit vectors (compute_misorientation, :11-20) are kept per voxel in S.ovec

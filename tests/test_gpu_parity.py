@@ -85,6 +85,29 @@ def test_sweep_vs_oracle_larger(oracle_mod, L, seed):
     assert abs(total - sw["total"]) <= RATE_RTOL * abs(sw["total"])
 
 
+@pytest.mark.parametrize("L,seed,fill", [(24, 1, 0.3), (40, 2, 0.05), (70, 3, 0.5), (8, 4, 0.9)])
+def test_sweep_variants_bit_identical(L, seed, fill):
+    """The streaming kernel (+ interface list) and the simple kernel produce identical row sums,
+    also after events were applied (incremental interface-list maintenance)."""
+    state, theta, phi, T, defects = random_lattice(L, seed, fill=fill)
+    e = _engine(L, 0.2)
+    e.upload(state, theta, phi, T, defects)
+    rs = np.random.RandomState(seed)
+    for rnd in range(3):
+        out = []
+        for v in (1, 0):
+            e.set_option("sweep_variant", v)
+            info = e.rate_sweep()
+            out.append((info,) + e.row_sums())
+        assert out[0][0] == out[1][0]
+        assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+        e.set_option("sweep_variant", 1)
+        n = 25
+        res = e.run_steps(rnd * n, n, 0.1, rs.random_sample(n), rs.random_sample(n), rs.random_sample(n * (L * L + 2)),
+                          rng_mode=0, thermal_mode=1)
+        assert res["status"] in (0, 1) and (res["done"] == n or res["status"] == 1)   # dense lattices run out of events
+
+
 def test_thermal_cet_fixtures():
     z = load("thermal")
     for L in (1, 2, 3, 7, 16):
