@@ -34,7 +34,7 @@ for p in (PKG, ROOT):
 
 L_FOR_GPUS = {1: 256, 2: 320, 4: 408, 8: 512}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-B_ALG_SWEEP = 9.0              # bytes/voxel/sweep: state u8 + T f64, each read once
+B_ALG_SWEEP = 10.0             # bytes/voxel/sweep: census class u16 + T f64, each read once
 IMPURITY_C, DEFECT_FRACTION, SEED = 0.2, 3e-3, 42
 
 

@@ -410,7 +410,7 @@ int launch_sweep(Handle* h, bool batch, hipEvent_t ev_a = nullptr, hipEvent_t ev
         hipLaunchKernelGGL(k_plane_reduce, dim3(3 * v.nloc), dim3(64), 0, h->stream, v, h->d_blocks, ss);
     }
     HIPCHK(hipGetLastError());
-    if (h->nranks > 1) {
+    if (h->comm) {
         const size_t per = (size_t)3 * (h->L / h->nranks) * sizeof(BlockEnt);
         NCCLCHK(g_rccl.AllGather((const char*)h->d_blocks + per * h->rank, h->d_blocks, per, ncclChar, h->comm, h->stream));
     }
@@ -425,7 +425,7 @@ int launch_select(Handle* h, const BatchCfg& cfg, double r_direct, int info_only
                        (const double*)h->d_u_pick, r_direct, (const double*)h->d_ktab,
                        h->d_events_all + h->my_first, info_only);
     HIPCHK(hipGetLastError());
-    if (h->nranks > 1 && !info_only) {
+    if (h->comm && !info_only) {
         NCCLCHK(g_rccl.AllGather((const char*)(h->d_events_all + h->rank), h->d_events_all, sizeof(cetkmc_event),
                                  ncclChar, h->comm, h->stream));
     }
@@ -442,7 +442,7 @@ int exchange_T_halo(Handle* h, int buf)
         HIPCHK(hipMemcpyAsync(b.Tbuf[buf], a.Tbuf[buf] + plane * a.v.nloc, 2 * plane * 8, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(a.Tbuf[buf] + plane * (a.v.nloc + 2), b.Tbuf[buf] + plane * 2, 2 * plane * 8, hipMemcpyDeviceToDevice, h->stream));
     }
-    if (h->nranks > 1) {
+    if (h->comm && h->nranks > 1) {
         Slab& s = h->slabs[0];
         double* T = s.Tbuf[buf];
         const size_t cnt = 2 * plane * 8;
