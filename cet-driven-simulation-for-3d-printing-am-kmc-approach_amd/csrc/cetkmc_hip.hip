@@ -118,7 +118,8 @@ struct Handle {
     int rank = 0, nranks = 1;
     bool swept = false;
     int sweep_variant = 1;
-    int ifc_blocks = 2048;     // grid of k_interface (grid-stride over the device-side list length)
+    int ifc_blocks = 64;       // grid of k_interface (grid-stride over the device-side list length)
+    int ifc_block = 256;
     size_t shmem_stream = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> prof;
@@ -197,6 +198,8 @@ int create_common(const cetkmc_params* p, int L, const std::vector<std::pair<int
     h->RJ = round_up(L, SWEEP_TJ) + 4;
     h->pitchS = round_up(KOFF + L + 4, 16);
     h->pitchT = round_up(L, 2);
+    if (const char* e = getenv("CETKMC_TPAD")) h->pitchT += 2 * atoi(e);   // experiment: row padding (doubles/2)
+    if (const char* e = getenv("CETKMC_IFC_BLOCK")) h->ifc_block = atoi(e);
     h->pitchC = round_up(KOFFC + L + 8, 8);
     h->shmem_stream = (size_t)((5 * (SWEEP_TJ + 4) * h->pitchC * 2 + 15) & ~15) + (226 + SWEEP_TJ * 3 * STREAM_MAXCH) * sizeof(double);
     if (h->shmem_stream > 160 * 1024) { delete h; return fail("L too large for the LDS ring"); }
@@ -354,6 +357,20 @@ int upload_impl(Handle* h, int i_begin, int i_end, const I* state, const double*
         if (phi) CHK(h2d_f64(h, s, s.v.phi, phi, i_begin, a, b));
         if (T) CHK(h2d_f64(h, s, s.Tbuf[h->cur], T, i_begin, a, b));
         if (theta || phi) hipLaunchKernelGGL(k_orient, dim3(1024), dim3(256), 0, h->stream, s.v);
+        if (state) {
+            // order the rebuilt list by (plane,row,column): consecutive lanes of k_interface then
+            // gather from neighbouring addresses
+            int n = 0;
+            HIPCHK(hipMemcpyAsync(&n, s.v.ifc_n, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            if (n > 1) {
+                std::vector<uint32_t> lst((size_t)n);
+                HIPCHK(hipMemcpy(lst.data(), s.v.ifc_list, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                std::sort(lst.begin(), lst.end());
+                HIPCHK(hipMemcpy(s.v.ifc_list, lst.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+            }
+            h->ifc_blocks = std::max(h->ifc_blocks, std::min(8192, (n + 255) / 256 + 64));
+        }
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -386,7 +403,7 @@ int launch_sweep(Handle* h, bool batch, hipEvent_t ev_a = nullptr, hipEvent_t ev
     const int njt = (h->L + SWEEP_TJ - 1) / SWEEP_TJ;
     if (h->sweep_variant == 1) {
         for (size_t s = 0; s < h->slabs.size(); ++s)
-            hipLaunchKernelGGL(k_interface, dim3(h->ifc_blocks), dim3(256), 0, h->stream, h->kp, view_of(h, (int)s), h->d_ktab, ss);
+            hipLaunchKernelGGL(k_interface, dim3(h->ifc_blocks * (256 / h->ifc_block)), dim3(h->ifc_block), 0, h->stream, h->kp, view_of(h, (int)s), h->d_ktab, ss);
     }
     if (ev_a) HIPCHK(hipEventRecord(ev_a, h->stream));
     for (size_t s = 0; s < h->slabs.size(); ++s) {
@@ -423,7 +440,7 @@ int launch_select(Handle* h, const BatchCfg& cfg, double r_direct, int info_only
     hipLaunchKernelGGL(k_select, dim3(1), dim3(256), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
                        (int)h->slabs.size(), h->L, h->PB, (const BlockEnt*)h->d_blocks, h->d_ss, cfg,
                        (const double*)h->d_u_pick, r_direct, (const double*)h->d_ktab,
-                       h->d_events_all + h->my_first, info_only);
+                       h->d_events_all + h->my_first, info_only, h->sweep_variant == 1 ? 1 : 0);
     HIPCHK(hipGetLastError());
     if (h->comm && !info_only) {
         NCCLCHK(g_rccl.AllGather((const char*)(h->d_events_all + h->rank), h->d_events_all, sizeof(cetkmc_event),
@@ -605,6 +622,7 @@ int cetkmc_set_option(void* handle, const char* key, int64_t value)
     if (!strcmp(key, "sweep_variant")) {
         if (value < 0 || value > 1) return fail("sweep_variant must be 0 (simple) or 1 (streaming, default)");
         h->sweep_variant = (int)value;
+        h->swept = false;
         return 0;
     }
     return fail(std::string("unknown option ") + key);

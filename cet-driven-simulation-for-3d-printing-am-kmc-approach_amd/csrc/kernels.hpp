@@ -410,7 +410,7 @@ __device__ __forceinline__ int heap_descend(const double* hs, const int* hf, int
 __global__ __launch_bounds__(256) void k_select(KParams P, const SlabView* __restrict__ slabs, int nslabs, int L,
                                                 int PB, const BlockEnt* __restrict__ blocks, StepState* ss,
                                                 BatchCfg cfg, const double* __restrict__ u_pick, double r_direct,
-                                                const double* __restrict__ ktab_g, cetkmc_event* my_event, int info_only)
+                                                const double* __restrict__ ktab_g, cetkmc_event* my_event, int info_only, int ifc_ready)
 {
     __shared__ double hs[2 * PMAX];
     __shared__ int hf[2 * PMAX];
@@ -485,14 +485,20 @@ __global__ __launch_bounds__(256) void k_select(KParams P, const SlabView* __res
     }
     __syncthreads();
     const int j = sh_j;
-    // voxels of row (i, c, j): re-evaluate
+    // voxels of row (i, c, j): re-evaluate.  Interface voxels are all listed (invariant of the
+    // interface list) and k_interface has left their full EMPTY/DIFF category sum in ifc_val.
     for (int k = tid; k < Pk; k += 256) {
         double sum = 0.0; int cnt = 0;
         if (k < L) {
             const int st = S.state[S.sidx(li, j, k)];
-            auto nb = [&](int mm) -> int { return S.state[S.sidx(li + nbi_rt(mm), j + nbj_rt(mm), k + nbk_rt(mm))]; };
-            auto emit = [&](int cat, int, double rate, int, int) { if (cat == c) { sum += rate; ++cnt; } };
-            eval_voxel(P, S, ktab, li, i, j, k, st, S.T[S.tidx(li, j, k)], nb, emit);
+            const int64_t t = S.tidx(li, j, k);
+            if (c != CAT_DEP && ifc_ready && S.ifc_in[t]) {
+                if ((c == CAT_EMPTY) == (st == 0)) { sum = S.ifc_val[t]; cnt = S.ifc_cnt[t]; }
+            } else {
+                auto nb = [&](int mm) -> int { return S.state[S.sidx(li + nbi_rt(mm), j + nbj_rt(mm), k + nbk_rt(mm))]; };
+                auto emit = [&](int cat, int, double rate, int, int) { if (cat == c) { sum += rate; ++cnt; } };
+                eval_voxel(P, S, ktab, li, i, j, k, st, S.T[t], nb, emit);
+            }
         }
         hs[Pk + k] = sum; hf[Pk + k] = cnt > 0; leafcnt[k] = cnt;
     }
@@ -546,8 +552,8 @@ __device__ __forceinline__ bool is_interface(const SlabView& S, int li, int j, i
     const int st = S.state[S.sidx(li, j, k)];
     if (st >= 128 || st == 4) return false;
     bool hit = false;
-#pragma unroll 1
-    for (int m = 0; m < 14; ++m) {
+#pragma unroll
+    for (int m = 0; m < 14; ++m) {          // unrolled: the 14 loads are issued together
         const int sm = S.state[S.sidx(li + nbi_rt(m), j + nbj_rt(m), k + nbk_rt(m))];
         hit |= (st == 0) ? (sm >= 1 && sm <= 3) : (sm == 0);
     }
@@ -586,26 +592,87 @@ __device__ __forceinline__ void ifc_touch(const SlabView& S, int i, int j, int k
     if (lp < 0 || lp >= S.nloc) return;                      // owned planes only
     if (is_interface(S, lp + 2, aj, ak)) ifc_append(S, lp, aj, ak);
 }
-// every step: EMPTY/DIFF category sum + count of every listed voxel, one voxel per lane
+// every step: EMPTY/DIFF category sum + count of every listed voxel, one voxel per lane.
+// Latency-bound gather kernel: all loads of a phase are issued together (own fields + 14
+// neighbour states, then 7 neighbours' vectors / temperatures at a time from clamped-safe
+// addresses), so a voxel costs ~3 memory round trips instead of one per event.
 __global__ __launch_bounds__(256) void k_interface(KParams P, SlabView S, const double* __restrict__ ktab_g,
                                                    const StepState* __restrict__ ss)
 {
     if (ss && ss->status) return;
     __shared__ double ktab[225];
-    if (threadIdx.x < 225) ktab[threadIdx.x] = ktab_g[threadIdx.x];
+    for (int t = threadIdx.x; t < 225; t += blockDim.x) ktab[t] = ktab_g[t];
     __syncthreads();
     const int n = *S.ifc_n;
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
         const unsigned v = S.ifc_list[q];
         const int lp = v >> 20, j = (v >> 10) & 1023, k = v & 1023;
-        const int li = lp + 2, i = S.gi0 + lp;
+        const int li = lp + 2;
+        const int64_t t = S.tidx(li, j, k);
         const int st = S.state[S.sidx(li, j, k)];
+        const double Tc = pymax(S.T[t], 1.0);
+        int s[14];
+#pragma unroll
+        for (int m = 0; m < 14; ++m) s[m] = S.state[S.sidx(li + nbi_rt(m), j + nbj_rt(m), k + nbk_rt(m))];
         double sum = 0.0;
         int cnt = 0;
-        auto nb = [&](int mm) -> int { return S.state[S.sidx(li + nbi_rt(mm), j + nbj_rt(mm), k + nbk_rt(mm))]; };
-        auto emit = [&](int cat, int, double rate, int, int) { if (cat != CAT_DEP) { sum += rate; ++cnt; } };
-        eval_voxel(P, S, ktab, li, i, j, k, st, S.T[S.tidx(li, j, k)], nb, emit);
-        const int64_t t = S.tidx(li, j, k);
+        if (st == 0) {
+            int n_nb = 0, n_imp = 0, n_src = 0;
+#pragma unroll
+            for (int m = 0; m < 14; ++m) { n_nb += (s[m] != OOB); n_imp += (s[m] == 2 || s[m] == 3); n_src += (s[m] >= 1 && s[m] <= 3); }
+            const double dT = P.T_melt - Tc;
+            if (dT > P.delta_T_c) {
+                const double rate = nuc_rate(P, ktab[n_nb * 15 + n_imp], dT, P.kT * Tc);
+                if (rate > P.rate_threshold && finite_d(rate)) { sum = rate; cnt = 1; }
+            }
+            if (n_src > 0) {
+                const AttCtx c = att_ctx(P, S, li, j, k, Tc);
+                unsigned mask = 0;
+#pragma unroll
+                for (int m = 0; m < 14; ++m) if (s[m] >= 1 && s[m] <= 3) mask |= 1u << m;
+                while (mask) {                                   // batches of 4 attachment sources
+                    int ms[4];
+                    double b[4][3];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        ms[u] = mask ? __builtin_ctz(mask) : -1;
+                        mask &= mask - 1;
+                        const int m = ms[u] < 0 ? 0 : ms[u];
+                        const double* p = S.ovec + 3 * (ms[u] < 0 ? t : S.tidx(li + nbi_rt(m), j + nbj_rt(m), k + nbk_rt(m)));
+                        b[u][0] = p[0]; b[u][1] = p[1]; b[u][2] = p[2];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (ms[u] >= 0) {
+                            int sn = 0;
+#pragma unroll
+                            for (int m = 0; m < 14; ++m) if (m == ms[u]) sn = s[m];
+                            const double rate = att_item(P, c, b[u][0], b[u][1], b[u][2], sn);
+                            if (rate > P.rate_threshold && finite_d(rate)) { sum = sum + rate; ++cnt; }
+                        }
+                    }
+                }
+            }
+        } else if (st != 4 && st < 128) {
+            int n_bonds = 0;
+            unsigned mask = 0;
+#pragma unroll
+            for (int m = 0; m < 14; ++m) { n_bonds += (s[m] != 0 && s[m] != OOB); if (s[m] == 0) mask |= 1u << m; }
+            if (mask) {
+                const DiffCtx c = diff_ctx(P, S, li, j, k, st, n_bonds, Tc);
+                double Tn[14];
+#pragma unroll
+                for (int m = 0; m < 14; ++m)                       // all neighbour temperatures in one round trip
+                    Tn[m] = S.T[(mask >> m) & 1u ? S.tidx(li + nbi_rt(m), j + nbj_rt(m), k + nbk_rt(m)) : t];
+#pragma unroll
+                for (int m = 0; m < 14; ++m) {
+                    if ((mask >> m) & 1u) {
+                        const double rate = diff_item(P, c, Tn[m]);
+                        if (rate > P.rate_threshold && finite_d(rate)) { sum = sum + rate; ++cnt; }
+                    }
+                }
+            }
+        }
         S.ifc_val[t] = sum;
         S.ifc_cnt[t] = (uint8_t)cnt;
     }

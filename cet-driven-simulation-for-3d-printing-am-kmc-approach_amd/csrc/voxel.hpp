@@ -154,52 +154,90 @@ __device__ __forceinline__ double exp_nonpos(double x)
 }
 
 // kmc_event_rates.py:126-130 with K_eff from the table.  The reference's two divisions
-// barrier = K/den; x = -barrier/kTT are evaluated as ONE: x = -K/(den*kTT) (differs from the
-// reference's rounding by <= 2 ulp of x, i.e. <= ~1e-15 relative in the rate), and the
+// barrier = K/den; x = -barrier/kTT are evaluated as x = -K * (1/(den*kTT)) with a Newton-refined
+// reciprocal (differs from the reference's rounding by a few ulp of x, i.e. <= ~1e-15 relative in
+// the rate), and the
 // exponential by exp_nonpos().  Every kernel uses this one function, so GPU-side sums are
 // mutually bit-consistent.
+__device__ __forceinline__ double rcp_nr(double d)
+{   // 1/d for normal positive d: hardware estimate + two Newton steps (~1 ulp, 5 instructions)
+    double r = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-d, r, 1.0);
+    return fma(r, e, r);
+}
 __device__ __forceinline__ double nuc_rate_s(double I0, double K, double dT, double kTT)
 {
     const double a = dT + 1e-6;
     const double den = pymax(a * a, 1e-6);
-    return I0 * exp_nonpos(-K / (den * kTT));
+    return I0 * exp_nonpos(-K * rcp_nr(den * kTT));
 }
 __device__ __forceinline__ double nuc_rate(const KParams& P, double K, double dT, double kTT)
 {
     return nuc_rate_s(P.I0, K, dT, kTT);
 }
-// kmc_event_rates.py:147-156: attachment of species sn from neighbour slot m to empty voxel (li,j,k).
+// kmc_event_rates.py:147-156: attachment to the empty voxel (li,j,k) from its W/Re/C neighbours.
 // The orientation unit vectors (compute_misorientation, :11-20) are kept per voxel in S.ovec
 // (written whenever theta/phi change), so the hot kernels need no sin/cos; and since
 // cos(arccos(d)) == d to 1 ulp, E_att = 0.5*E_b*(1 - cos(mis)) is evaluated as 0.5*E_b*(1 - d)
 // with d the clamped dot product (:21-22).  Rates agree with the reference to ~1e-15 relative.
-__device__ __forceinline__ double att_rate(const KParams& P, const SlabView& S, int li, int j, int k,
-                                           int di, int dj, int dk, int sn, double Tc)
+// Split into a per-voxel context and a per-neighbour item so that every kernel (row re-evaluation,
+// interface list, event enumeration) performs the identical arithmetic.
+struct AttCtx { double a0, a1, a2, aniso, kTT; };
+__device__ __forceinline__ AttCtx att_ctx(const KParams& P, const SlabView& S, int li, int j, int k, double Tc)
 {
     const int L = S.L;
     const double* a = S.ovec + 3 * S.tidx(li, j, k);
-    const double* b = S.ovec + 3 * S.tidx(li + di, j + dj, k + dk);
-    double dot = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
-    dot = pymax(pymin(dot, 1.0), -1.0);
     const int km = k - 1 > 0 ? k - 1 : 0;
     const int kp = k + 1 < L - 1 ? k + 1 : L - 1;
     const double grad_z = (S.T[S.tidx(li, j, kp)] - S.T[S.tidx(li, j, km)]) * 0.5;
     const double gf = pymax(0.0, grad_z) / pymax(P.T_melt - Tc, 1.0);
-    const double E_att = 0.5 * P.E_b[sn - 1] * (1.0 - dot);
-    return P.nu * exp(-E_att / (P.kT * Tc)) * (1.0 + P.anisotropy * gf);
+    AttCtx c;
+    c.a0 = a[0]; c.a1 = a[1]; c.a2 = a[2];
+    c.aniso = 1.0 + P.anisotropy * gf;
+    c.kTT = P.kT * Tc;
+    return c;
 }
-// kmc_event_rates.py:93-107: diffusion of the atom st at (li,j,k) into the empty neighbour slot
-__device__ __forceinline__ double diff_rate(const KParams& P, const SlabView& S, int li, int j, int k,
-                                            int di, int dj, int dk, int st, int n_bonds, double Tc)
+__device__ __forceinline__ double att_item(const KParams& P, const AttCtx& c, double b0, double b1, double b2, int sn)
+{
+    double dot = c.a0 * b0 + c.a1 * b1 + c.a2 * b2;
+    dot = pymax(pymin(dot, 1.0), -1.0);
+    const double E_att = 0.5 * P.E_b[sn - 1] * (1.0 - dot);
+    return P.nu * exp(-E_att / c.kTT) * c.aniso;
+}
+__device__ __forceinline__ double att_rate(const KParams& P, const SlabView& S, int li, int j, int k,
+                                           int di, int dj, int dk, int sn, double Tc)
+{
+    const AttCtx c = att_ctx(P, S, li, j, k, Tc);
+    const double* b = S.ovec + 3 * S.tidx(li + di, j + dj, k + dk);
+    return att_item(P, c, b[0], b[1], b[2], sn);
+}
+// kmc_event_rates.py:93-107: diffusion of the atom st at (li,j,k) into its empty neighbours
+struct DiffCtx { double arr, Tc; };
+__device__ __forceinline__ DiffCtx diff_ctx(const KParams& P, const SlabView& S, int li, int j, int k, int st, int n_bonds, double Tc)
 {
     const int ia = (st == 1) ? 0 : (st == 2) ? 1 : 2;
     const double defect_factor = 1.0 + (double)S.defects[S.sidx(li, j, k)];
     const double E_tot = pymax(P.E_diff[ia] + 0.1 * (double)n_bonds * P.E_b[ia], 0.0);
-    const double Tn = pymax(S.T[S.tidx(li + di, j + dj, k + dk)], 1.0);
-    const double dTn = fabs(Tc - Tn);
+    DiffCtx c;
+    c.arr = exp(-defect_factor * E_tot / (P.kT * Tc));
+    c.Tc = Tc;
+    return c;
+}
+__device__ __forceinline__ double diff_item(const KParams& P, const DiffCtx& c, double Tn_raw)
+{
+    const double Tn = pymax(Tn_raw, 1.0);
+    const double dTn = fabs(c.Tc - Tn);
     const double denom = pymax(P.T_melt - Tn, 1.0);
     const double grad = 1.0 + 0.1 * dTn / denom;
-    return P.nu * grad * exp(-defect_factor * E_tot / (P.kT * Tc));
+    return P.nu * grad * c.arr;
+}
+__device__ __forceinline__ double diff_rate(const KParams& P, const SlabView& S, int li, int j, int k,
+                                            int di, int dj, int dk, int st, int n_bonds, double Tc)
+{
+    const DiffCtx c = diff_ctx(P, S, li, j, k, st, n_bonds, Tc);
+    return diff_item(P, c, S.T[S.tidx(li + di, j + dj, k + dk)]);
 }
 
 // Evaluate the events of voxel (i,j,k) (local plane li) whose own state is `st` and raw
@@ -236,12 +274,16 @@ __device__ __forceinline__ void eval_voxel(const KParams& P, const SlabView& S, 
             double rate = nuc_rate(P, ktab[n_nb * 15 + n_imp], dT, P.kT * Tc);
             if (rate > P.rate_threshold && finite_d(rate)) emit(CAT_EMPTY, EV_NUC, rate, -1, 1);
         }
-        while (m_src) {
-            const int m = __builtin_ctz(m_src);
-            m_src &= m_src - 1;
-            const int sm = nb(m);
-            double rate = att_rate(P, S, li, j, k, nbi_rt(m), nbj_rt(m), nbk_rt(m), sm, Tc);
-            if (rate > P.rate_threshold && finite_d(rate)) emit(CAT_EMPTY, EV_ATT, rate, m, sm);
+        if (m_src) {
+            const AttCtx c = att_ctx(P, S, li, j, k, Tc);
+            while (m_src) {
+                const int m = __builtin_ctz(m_src);
+                m_src &= m_src - 1;
+                const int sm = nb(m);
+                const double* b = S.ovec + 3 * S.tidx(li + nbi_rt(m), j + nbj_rt(m), k + nbk_rt(m));
+                double rate = att_item(P, c, b[0], b[1], b[2], sm);
+                if (rate > P.rate_threshold && finite_d(rate)) emit(CAT_EMPTY, EV_ATT, rate, m, sm);
+            }
         }
     } else if (st != 4) {
         int n_bonds = 0;
@@ -252,11 +294,14 @@ __device__ __forceinline__ void eval_voxel(const KParams& P, const SlabView& S, 
             n_bonds += (sm != 0 && sm != OOB);
             if (sm == 0) m_empty |= 1u << m;
         }
-        while (m_empty) {
-            const int m = __builtin_ctz(m_empty);
-            m_empty &= m_empty - 1;
-            double rate = diff_rate(P, S, li, j, k, nbi_rt(m), nbj_rt(m), nbk_rt(m), st, n_bonds, Tc);
-            if (rate > P.rate_threshold && finite_d(rate)) emit(CAT_DIFF, EV_DIFF, rate, m, st);
+        if (m_empty) {
+            const DiffCtx c = diff_ctx(P, S, li, j, k, st, n_bonds, Tc);
+            while (m_empty) {
+                const int m = __builtin_ctz(m_empty);
+                m_empty &= m_empty - 1;
+                double rate = diff_item(P, c, S.T[S.tidx(li + nbi_rt(m), j + nbj_rt(m), k + nbk_rt(m))]);
+                if (rate > P.rate_threshold && finite_d(rate)) emit(CAT_DIFF, EV_DIFF, rate, m, st);
+            }
         }
     }
 }

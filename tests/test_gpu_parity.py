@@ -326,3 +326,32 @@ def test_transfers_and_errors():
         e3.select(0.0)
     res = e3.run_steps(0, 5, 0.0, np.full(5, 0.5), None, np.zeros(64), thermal_mode=0)
     assert res["status"] == 1 and res["done"] == 0     # kmc_simulation.py:260-262
+
+
+@pytest.mark.parametrize("L,n_slabs,n", [(128, 4, 40), (256, 2, 12)])
+def test_full_size_determinism_and_slab_invariance(L, n_slabs, n):
+    """BASELINE-size lattices (config-3 workload: pre-filled k<L/4, moving melt pool, latent heat,
+    counter-mode species): run-to-run determinism and slab-count invariance of every per-step
+    total, chosen event and of the final fields -- size-independent properties that need no oracle."""
+    import cetkmc
+    from cetkmc import synthetic
+    st, th, ph, T, df = synthetic.planes(L, 0, L, seed=7)
+    q = synthetic.laser_planes(L, 0, n)
+    rs = np.random.RandomState(2)
+    u_pick, u_def, u_np = rs.random_sample(n), rs.random_sample(n), rs.random_sample(2 * n + 2)
+    outs = []
+    for ns in (1, 1, n_slabs):
+        e = cetkmc.Engine(L, impurity_c=0.2, n_slabs=ns)
+        e.upload_planes(0, L, st, th, ph, T, df)
+        e.set_prev_state(None)
+        r = e.run_steps(0, n, 3e-3, u_pick, u_def, u_np, rng_mode=1, seed=11, thermal_mode=2, q_planes=q)
+        assert r["done"] == n and r["status"] == 0
+        d = e.download_planes(0, L, state=True, theta=True, T=True)
+        outs.append((r["totals"].tobytes(), r["events"].tobytes(), r["n_events"].tobytes(),
+                     d["state"].tobytes(), d["theta"].tobytes(), d["T"].tobytes()))
+        e.close()
+        # conservation: one executed event per step, every event changes at most 2 voxels
+        changed = int(np.count_nonzero(d["state"] != st))
+        assert 0 < changed <= 2 * n
+    assert outs[0] == outs[1]          # determinism
+    assert outs[0] == outs[2]          # slab-count invariance (bit-identical sums and picks)

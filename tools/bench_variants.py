@@ -20,6 +20,13 @@ fill = float(os.environ.get("FILL", "0.25"))
 st, th, ph, T, df = synthetic.planes(L, 0, L, seed=42, fill_frac=fill)
 print("fill_frac", fill, flush=True)
 e.upload_planes(0, L, st, th, ph, T, df)
+evolve = int(os.environ.get("EVOLVE", "0"))
+if evolve:
+    rs = np.random.RandomState(1)
+    q = synthetic.laser_planes(L, 0, evolve)
+    r = e.run_steps(0, evolve, 3e-3, rs.random_sample(evolve), rs.random_sample(evolve), rs.random_sample(2 * evolve + 2),
+                    rng_mode=1, seed=42, thermal_mode=int(os.environ.get("THERMAL", "2")), q_planes=q)
+    print("evolved", r["done"], "steps, status", r["status"], flush=True)
 ref = None
 for v in variants:
     e.set_option("sweep_variant", v)
