@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile_round.sh run (gpurun_out/<tag>_*) into profiles/:
+   <tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats), <tag>_bench.json, <tag>_summary.json
+   (per-kernel average duration + HBM traffic from the FETCH_SIZE / WRITE_SIZE PMC passes).
+HBM traffic per launch = 2*FETCH_SIZE + WRITE_SIZE (KB -> bytes): on gfx950 FETCH_SIZE reports half
+of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section); the x2 is applied to the
+streaming kernels (k_sweep_stream, k_thermal: 16-B-per-lane loads) and NOT to the narrow-gather
+kernels, whose calibration is unknown (reported raw, flagged)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import statistics
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def one(pattern):
+    g = glob.glob(os.path.join(src, pattern))
+    return g[0] if g else None
+
+
+stats = one(f"{tag}_stats/*/*kernel_stats.csv")
+summary = {"tag": tag, "kernels": {}}
+if stats:
+    shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+    for r in csv.DictReader(open(stats)):
+        name = r["Name"].split("(")[0].replace("cetkmc::", "").replace("void ", "")
+        summary["kernels"][name] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
+                                    "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3,
+                                    "pct": float(r["Percentage"])}
+for which in ("fetch", "write"):
+    f = one(f"{tag}_pmc_{which}/*/*counter_collection.csv")
+    if not f:
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0].replace("cetkmc::", "").replace("void ", "")
+        agg[name].append(float(r["Counter_Value"]))
+    for name, v in agg.items():
+        summary["kernels"].setdefault(name, {})[f"{which}_size_kb_median"] = statistics.median(v)
+for name, k in summary["kernels"].items():
+    if "fetch_size_kb_median" in k and "write_size_kb_median" in k:
+        wide = name in ("k_sweep_stream", "k_thermal")
+        k["hbm_bytes_per_launch"] = (2.0 if wide else 1.0) * k["fetch_size_kb_median"] * 1024 + k["write_size_kb_median"] * 1024
+        k["fetch_x2_applied"] = wide
+for f in (f"{tag}_bench.json", f"{tag}_bench_under_rocprof.json"):
+    p = os.path.join(src, f)
+    if os.path.exists(p) and os.path.getsize(p):
+        shutil.copy(p, os.path.join(dst, f))
+        summary[f.replace(f"{tag}_", "").replace(".json", "")] = json.loads(open(p).read().strip().splitlines()[-1])
+json.dump(summary, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
+print(json.dumps({k: v for k, v in summary["kernels"].items() if "avg_us" in v and v.get("pct", 0) > 1}, indent=1))
