@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--L", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the multi-process code path (gloo rendezvous + RCCL communicator) even with one rank")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -103,9 +105,11 @@ def main():
 
     dist = None
     uid = None
-    if N > 1:
+    if N > 1 or a.force_dist:
         import torch
         import torch.distributed as dist
+        if "RANK" not in os.environ:             # plain `python bench.py --force-dist`
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
         dist.init_process_group("gloo")          # control plane only (id exchange, barrier, max)
         box = [cetkmc.Engine.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)

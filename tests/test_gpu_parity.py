@@ -355,3 +355,25 @@ def test_full_size_determinism_and_slab_invariance(L, n_slabs, n):
         assert 0 < changed <= 2 * n
     assert outs[0] == outs[1]          # determinism
     assert outs[0] == outs[2]          # slab-count invariance (bit-identical sums and picks)
+
+
+def test_config2_constant_T_128(oracle_mod):
+    """BASELINE config 2: 128^3, constant T=3000 K, pre-filled k<32: rate sweep + selection only,
+    against the oracle on the full lattice (counts exact, row sums/total <= 1e-11, same picks)."""
+    import cetkmc
+    from cetkmc import synthetic
+    L = 128
+    st, th, ph, T, df = synthetic.planes(L, 0, L, seed=1, constant_T=3000.0)
+    e = cetkmc.Engine(L, impurity_c=0.2)
+    e.upload_planes(0, L, st, th, ph, T, df)
+    lat = oracle_mod.Lattice(st, th, ph, T, df, impurity_c=0.2)
+    sw = lat.sweep()
+    total, n_events, n_dep = e.rate_sweep()
+    rs, rc = e.row_sums()
+    assert (n_events, n_dep) == (sw["n_events"], sw["n_dep"]) and np.array_equal(rc, sw["rowcnt"])
+    assert relerr(rs, sw["rowsum"]).max() <= RATE_RTOL
+    assert abs(total - sw["total"]) <= RATE_RTOL * sw["total"]
+    for u in np.random.RandomState(4).random_sample(100):
+        want = lat.select_tree(sw["blocksum"], sw["blockcnt"], sw["rowsum"], sw["rowcnt"], u * sw["total"])
+        got = e.select(u * total)
+        assert (got.type, tuple(got.pos), tuple(got.target)) == (want.type, tuple(want.pos), tuple(want.target)), u
