@@ -183,11 +183,11 @@ def main():
     n_own = (eng.i1 - eng.i0) * L * L
     achieved = B_ALG_SWEEP * n_own / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
     traffic, traffic_src = None, None
-    for cand in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_summary.json")), reverse=True):
+    for summary_path in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_summary.json")), reverse=True):
         try:
-            kk = json.load(open(cand))["kernels"]["k_sweep_stream"]
+            kk = json.load(open(summary_path))["kernels"]["k_sweep_stream"]
             if N == 1 and L == 256 and "hbm_bytes_per_launch" in kk:
-                traffic, traffic_src = kk["hbm_bytes_per_launch"], os.path.relpath(cand, ROOT)
+                traffic, traffic_src = kk["hbm_bytes_per_launch"], os.path.relpath(summary_path, ROOT)
                 break
         except Exception:
             pass

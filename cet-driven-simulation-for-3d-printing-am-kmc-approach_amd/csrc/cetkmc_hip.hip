@@ -118,6 +118,8 @@ struct Handle {
     int rank = 0, nranks = 1;
     bool swept = false;
     int sweep_variant = 1;
+    int thermal_variant = 1;   // 1 = plane-marching LDS kernel, 0 = one thread per voxel
+    int therm_ni = THERM_NI;   // planes per block of the marching kernel
     int ifc_blocks = 64;       // grid of k_interface (grid-stride over the device-side list length)
     int ifc_block = 256;
     size_t shmem_stream = 0;
@@ -482,14 +484,21 @@ int launch_thermal(Handle* h, double dt, int laser, const double* d_q, int use_l
     ThermalCfg C{};
     C.dt = dt; C.alpha = h->p.alpha; C.inv_dx2 = h->p.inv_dx2; C.clip_lo = h->p.T_clip_lo; C.clip_hi = h->p.T_clip_hi;
     C.T_nan = h->p.T_nan; C.rho_cp = h->p.rho_cp; C.latent_coef = h->p.latent_coef;
-    C.laser = laser; C.use_latent = use_latent; C.scrub = scrub;
+    C.laser = laser; C.use_latent = use_latent; C.scrub = scrub; C.ni = h->therm_ni;
     const int nxt = h->cur ^ 1;
     for (size_t s = 0; s < h->slabs.size(); ++s) {
         SlabView v = view_of(h, (int)s);
-        dim3 grid((h->L + 255) / 256, h->L, v.nloc);
-        hipLaunchKernelGGL(k_thermal, grid, dim3(256), 0, h->stream, v, (const double*)h->slabs[s].Tbuf[h->cur],
-                           h->slabs[s].Tbuf[nxt], (const uint8_t*)h->slabs[s].prev, d_q, C,
-                           batch ? (const StepState*)h->d_ss : nullptr);
+        if (h->thermal_variant == 1) {
+            dim3 grid((h->L + THERM_KT - 1) / THERM_KT, (h->L + THERM_TJ - 1) / THERM_TJ, (v.nloc + h->therm_ni - 1) / h->therm_ni);
+            hipLaunchKernelGGL(k_thermal_march, grid, dim3(256), 0, h->stream, v, (const double*)h->slabs[s].Tbuf[h->cur],
+                               h->slabs[s].Tbuf[nxt], (const uint8_t*)h->slabs[s].prev, d_q, C,
+                               batch ? (const StepState*)h->d_ss : nullptr);
+        } else {
+            dim3 grid((h->L + 255) / 256, h->L, v.nloc);
+            hipLaunchKernelGGL(k_thermal, grid, dim3(256), 0, h->stream, v, (const double*)h->slabs[s].Tbuf[h->cur],
+                               h->slabs[s].Tbuf[nxt], (const uint8_t*)h->slabs[s].prev, d_q, C,
+                               batch ? (const StepState*)h->d_ss : nullptr);
+        }
     }
     HIPCHK(hipGetLastError());
     CHK(exchange_T_halo(h, nxt));
@@ -623,6 +632,16 @@ int cetkmc_set_option(void* handle, const char* key, int64_t value)
         if (value < 0 || value > 1) return fail("sweep_variant must be 0 (simple) or 1 (streaming, default)");
         h->sweep_variant = (int)value;
         h->swept = false;
+        return 0;
+    }
+    if (!strcmp(key, "thermal_planes_per_block")) {
+        if (value < 1 || value > 64) return fail("thermal_planes_per_block must be 1..64");
+        h->therm_ni = (int)value;
+        return 0;
+    }
+    if (!strcmp(key, "thermal_variant")) {
+        if (value < 0 || value > 1) return fail("thermal_variant must be 0 (simple) or 1 (marching, default)");
+        h->thermal_variant = (int)value;
         return 0;
     }
     return fail(std::string("unknown option ") + key);

@@ -802,7 +802,7 @@ __global__ __launch_bounds__(64) void k_apply_direct(const SlabView* __restrict_
 // ---- thermal -------------------------------------------------------------------------------
 struct ThermalCfg {
     double dt, alpha, inv_dx2, clip_lo, clip_hi, T_nan, rho_cp, latent_coef;
-    int laser, use_latent, scrub;
+    int laser, use_latent, scrub, ni;
 };
 __device__ __forceinline__ double scrub_T(double x, double T_nan, int on)
 {   // np.nan_to_num(T, nan=T_SUB), kmc_simulation.py:249
@@ -851,6 +851,107 @@ __global__ __launch_bounds__(256) void k_thermal(SlabView S, const double* __res
     double v = nt < C.clip_lo ? C.clip_lo : nt;                             // np.clip :105,117
     v = v > C.clip_hi ? C.clip_hi : v;
     Tout[c] = v;
+}
+
+// k_thermal_march: same arithmetic as k_thermal, 2.5-D blocked.  One block owns THERM_TJ rows x 256
+// columns and marches over THERM_NI planes: the planes i-1, i, i+1 of its own voxels live in registers
+// (8 voxels per thread), plane i additionally in an LDS tile with a one-voxel rim for the j+-1 / k+-1
+// neighbours.  Every T value is read ~1.4x and written once (k_thermal: 7 reads through L2).
+constexpr int THERM_TJ = 8, THERM_NI = 4, THERM_KT = 256;
+__global__ __launch_bounds__(256) void k_thermal_march(SlabView S, const double* __restrict__ Tin, double* __restrict__ Tout,
+                                                       const uint8_t* __restrict__ prev_state, const double* __restrict__ q_top,
+                                                       ThermalCfg C, const StepState* __restrict__ ss)
+{
+    constexpr int TJ = THERM_TJ, KT = THERM_KT, LW = KT + 2;
+    __shared__ double tile[(TJ + 2) * LW];
+    const int L = S.L;
+    const int tid = threadIdx.x;
+    const int kc = blockIdx.x * KT, j0 = blockIdx.y * TJ;
+    const int lp0 = blockIdx.z * C.ni, lp1 = min(lp0 + C.ni, S.nloc);
+    const bool passthrough = ss && ss->status;
+    const int col = 2 * (tid & 127), rbase = tid >> 7;          // thread: columns kc+col, kc+col+1 of rows rbase+2q
+    const int k0 = kc + col;
+    auto ldT = [&](int li, int j, int k) { return scrub_T(Tin[S.tidx(li, j, k)], C.T_nan, C.scrub && !passthrough); };
+    auto lplane = [&](int i) { return (i < 0 ? 0 : (i > L - 1 ? L - 1 : i)) - (S.gi0 - 2); };   // clamped global plane -> local
+    double prv[4][2], cur[4][2], nxt[4][2];
+    auto load_own = [&](int li, double (&dst)[4][2]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = j0 + rbase + 2 * q;
+            dst[q][0] = dst[q][1] = 0.0;
+            if (j < L && k0 < L) {
+                const double2 v = *reinterpret_cast<const double2*>(Tin + S.tidx(li, j, k0));
+                dst[q][0] = scrub_T(v.x, C.T_nan, C.scrub && !passthrough);
+                dst[q][1] = scrub_T(v.y, C.T_nan, C.scrub && !passthrough);
+            }
+        }
+    };
+    load_own(lplane(S.gi0 + lp0 - 1), prv);
+    load_own(lp0 + 2, cur);
+    const double dtm = C.dt > 1e-12 ? C.dt : 1e-12;
+#pragma unroll 1
+    for (int lp = lp0; lp < lp1; ++lp) {
+        const int li = lp + 2, i = S.gi0 + lp;
+        load_own(lplane(i + 1), nxt);
+        // plane i into LDS: own values, then the rim (rows j0-1 / j0+TJ, columns kc-1 / kc+KT), edge-replicated
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double* row = tile + (rbase + 2 * q + 1) * LW + 1 + col;
+            row[0] = cur[q][0]; row[1] = cur[q][1];
+        }
+        for (int e = tid; e < 2 * KT + 2 * (TJ + 2); e += 256) {
+            int tr, tc;                                          // tile coordinates of a rim cell
+            if (e < 2 * KT) { tr = (e < KT) ? 0 : TJ + 1; tc = 1 + (e % KT); }
+            else { const int f = e - 2 * KT; tr = f >> 1; tc = (f & 1) ? KT + 1 : 0; }
+            int j = j0 + tr - 1, kk = kc + tc - 1;
+            j = j < 0 ? 0 : (j > L - 1 ? L - 1 : j);
+            kk = kk < 0 ? 0 : (kk > L - 1 ? L - 1 : kk);
+            tile[tr * LW + tc] = ldT(li, j, kk);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = rbase + 2 * q, j = j0 + r;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = k0 + h;
+                if (j < L && k < L) {
+                    const int64_t c = S.tidx(li, j, k);
+                    if (passthrough) { Tout[c] = Tin[c]; continue; }
+                    const double tc = cur[q][h];
+                    // edge replication inside the lattice: the rim already holds clamped values, but an
+                    // interior tile edge that coincides with the lattice edge must replicate too
+                    const double* cell = tile + (r + 1) * LW + 1 + col + h;
+                    const double jm = (j > 0) ? cell[-LW] : tc, jp = (j < L - 1) ? cell[LW] : tc;
+                    const double km = (k > 0) ? cell[-1] : tc, kp = (k < L - 1) ? cell[1] : tc;
+                    const double d0 = tc * -2.0 + (prv[q][h] + nxt[q][h]);
+                    const double d1 = tc * -2.0 + (jm + jp);
+                    const double d2 = tc * -2.0 + (km + kp);
+                    const double lap = ((d0 + d1) + d2) * C.inv_dx2;
+                    double nt;
+                    if (!C.laser) {
+                        nt = tc + (C.dt * C.alpha) * lap;
+                    } else {
+                        const double qv = (i == L - 1) ? q_top[(int64_t)j * L + k] : 0.0;
+                        double dF = 0.0;
+                        if (C.use_latent) {
+                            const int64_t sc = S.sidx(li, j, k);
+                            dF = (prev_state[sc] == 0 && S.state[sc] != 0) ? 1.0 : 0.0;
+                        }
+                        dF = dF / dtm;
+                        const double dTdt = C.alpha * lap + qv / C.rho_cp + C.latent_coef * dF;
+                        nt = tc + C.dt * dTdt;
+                    }
+                    double v = nt < C.clip_lo ? C.clip_lo : nt;
+                    v = v > C.clip_hi ? C.clip_hi : v;
+                    Tout[c] = v;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { prv[q][0] = cur[q][0]; prv[q][1] = cur[q][1]; cur[q][0] = nxt[q][0]; cur[q][1] = nxt[q][1]; }
+    }
 }
 
 // ---- layout conversion -----------------------------------------------------------------------

@@ -377,3 +377,29 @@ def test_config2_constant_T_128(oracle_mod):
         want = lat.select_tree(sw["blocksum"], sw["blockcnt"], sw["rowsum"], sw["rowcnt"], u * sw["total"])
         got = e.select(u * total)
         assert (got.type, tuple(got.pos), tuple(got.target)) == (want.type, tuple(want.pos), tuple(want.target)), u
+
+
+@pytest.mark.parametrize("L,n_slabs", [(5, 1), (19, 2), (64, 1), (130, 3), (300, 1)])
+def test_thermal_kernel_variants_identical(L, n_slabs):
+    """Plane-marching LDS thermal kernel == one-thread-per-voxel kernel, bit for bit (cet + laser + latent)."""
+    rs = np.random.RandomState(L)
+    T = rs.uniform(2700.0, 4100.0, (L, L, L))
+    T[rs.random_sample((L, L, L)) < 0.01] = np.nan
+    state = (rs.random_sample((L, L, L)) < 0.3).astype(np.int64) * rs.randint(1, 5, (L, L, L))
+    prev = state * (rs.random_sample((L, L, L)) < 0.7)
+    q = rs.uniform(0, 1e15, (L, L))
+    z = np.zeros((L, L, L))
+    outs = []
+    for v in (0, 1):
+        e = _engine(L, n_slabs=n_slabs)
+        e.set_option("thermal_variant", v)
+        e.upload(state, z, z, T, state * 0)
+        e.set_prev_state(prev)
+        e.thermal_cet(1e-6, scrub_nan=True)
+        a = e.download()["T"]
+        e.thermal_laser(1e-6, q, use_latent=True, scrub_nan=False)
+        b = e.download()["T"]
+        e.thermal_cet(3e-7, scrub_nan=False)
+        outs.append((a, b, e.download()["T"]))
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y)

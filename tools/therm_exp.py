@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Timing of the thermal kernel variants (GPU box).  usage: therm_exp.py [L]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "cet-driven-simulation-for-3d-printing-am-kmc-approach_amd"))
+import cetkmc
+from cetkmc import synthetic
+L = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+e = cetkmc.Engine(L, impurity_c=0.2)
+st, th, ph, T, df = synthetic.planes(L, 0, L, seed=42)
+e.upload_planes(0, L, st, th, ph, T, df)
+q = synthetic.laser_planes(L, 0, 1)[0]
+for variant, ni in ((0, 16), (1, 1), (1, 2), (1, 4), (1, 8), (1, 16), (1, 32)):
+    e.set_option("thermal_variant", variant)
+    e.set_option("thermal_planes_per_block", ni)
+    for mode in ("cet", "laser"):
+        ts = []
+        for rep in range(6):
+            e.sync(); t0 = time.perf_counter()
+            for _ in range(5):
+                if mode == "cet":
+                    e.thermal_cet(1e-6, True)
+                else:
+                    e.thermal_laser(1e-6, q, use_latent=True)
+            e.sync(); ts.append((time.perf_counter() - t0) / 5)
+        print(f"variant {variant} ni {ni:2d} {mode:5s}: {min(ts)*1e6:7.1f} us (host-timed, incl. launch+sync)", flush=True)
