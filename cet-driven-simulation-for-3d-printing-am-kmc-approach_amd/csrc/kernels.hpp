@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void k_sweep_stream(StreamArgs A, const double
                                 if (dT > A.delta_T_c) {
                                     const int n_nb = f & 15, n_imp = (f >> 12) & 15;
                                     const double rate = nuc_rate_s(A.I0, ktab[n_nb * 15 + n_imp], dT, A.kT * Tc);
-                                    if (rate > A.rate_threshold && finite_d(rate)) { ev = rate; ++cemp; }
+                                    if (rate > A.rate_threshold) { ev = rate; ++cemp; }   // <= I0: always finite
                                 }
                             }
                         } else if ((oc & 0x100u) && (f & 0x00F0u)) { // atom with empty neighbours

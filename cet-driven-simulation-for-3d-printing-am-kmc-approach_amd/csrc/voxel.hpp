@@ -130,6 +130,14 @@ __device__ __forceinline__ double dep_rate(const KParams& P, double Tc)
 // Taylor polynomial in Horner form (truncation 4e-18), scaled by 2^n.  About 1 ulp; no overflow path
 // (x <= 0) and underflow falls out of v_ldexp_f64.  Used for the nucleation rate, whose argument is
 // -barrier/(kT*T) <= 0 by construction.
+// d = a*b + c as ONE v_fma_f64 (hipcc otherwise expands a Horner step with a constant addend into
+// v_mov_b64 + v_fmac_f64, doubling the instruction count of the polynomial)
+__device__ __forceinline__ double fma1(double a, double b, double c)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 __device__ __forceinline__ double exp_nonpos(double x)
 {
     x = fmax(x, -1000.0);
@@ -137,16 +145,16 @@ __device__ __forceinline__ double exp_nonpos(double x)
     double r = fma(n, -6.93147180369123816490e-01, x);
     r = fma(n, -1.90821492927058770002e-10, r);
     double p = 1.6059043836821613e-10;                 // 1/13!
-    p = fma(p, r, 2.08767569878681e-09);               // 1/12!
-    p = fma(p, r, 2.505210838544172e-08);              // 1/11!
-    p = fma(p, r, 2.755731922398589e-07);              // 1/10!
-    p = fma(p, r, 2.7557319223985893e-06);             // 1/9!
-    p = fma(p, r, 2.48015873015873e-05);               // 1/8!
-    p = fma(p, r, 1.984126984126984e-04);              // 1/7!
-    p = fma(p, r, 1.388888888888889e-03);              // 1/6!
-    p = fma(p, r, 8.333333333333333e-03);              // 1/5!
-    p = fma(p, r, 4.1666666666666664e-02);             // 1/4!
-    p = fma(p, r, 1.6666666666666666e-01);             // 1/3!
+    p = fma1(p, r, 2.08767569878681e-09);              // 1/12!
+    p = fma1(p, r, 2.505210838544172e-08);             // 1/11!
+    p = fma1(p, r, 2.755731922398589e-07);             // 1/10!
+    p = fma1(p, r, 2.7557319223985893e-06);            // 1/9!
+    p = fma1(p, r, 2.48015873015873e-05);              // 1/8!
+    p = fma1(p, r, 1.984126984126984e-04);             // 1/7!
+    p = fma1(p, r, 1.388888888888889e-03);             // 1/6!
+    p = fma1(p, r, 8.333333333333333e-03);             // 1/5!
+    p = fma1(p, r, 4.1666666666666664e-02);            // 1/4!
+    p = fma1(p, r, 1.6666666666666666e-01);            // 1/3!
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
