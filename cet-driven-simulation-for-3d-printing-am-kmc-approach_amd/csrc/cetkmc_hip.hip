@@ -93,7 +93,9 @@ struct Handle {
     KParams kp{};
     int L = 0, Pk = 1, PB = 1, RJ = 0, pitchS = 0, pitchT = 0, pitchC = 0;
     int dev = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;
+    hipEvent_t ev_swept = nullptr, ev_ifc = nullptr;
+    int overlap_ifc = 0;       // speculative k_interface of step s+1 overlapped with reduce/select of step s (measured: no gain)
     std::vector<Slab> slabs;
     SlabView* d_views[2] = {nullptr, nullptr};   // per T-buffer parity
     int cur = 0;                                 // current T buffer
@@ -208,6 +210,9 @@ int create_common(const cetkmc_params* p, int L, const std::vector<std::pair<int
     HIPCHK(hipFuncSetAttribute((const void*)k_sweep_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->shmem_stream));
     h->dev = dev; h->G = G; h->my_first = my_first;
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_swept, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_ifc, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&h->ev0));
     HIPCHK(hipEventCreate(&h->ev1));
     h->own_i0 = ranges.front().first;
@@ -397,16 +402,23 @@ int download_impl(Handle* h, int i_begin, int i_end, I* state, double* theta, do
 }
 
 // ---- per-step launches (all asynchronous on h->stream) -----------------------------------
-int launch_sweep(Handle* h, bool batch, hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr)
+int launch_interface(Handle* h, bool batch, hipStream_t st)
+{
+    const StepState* ss = batch ? h->d_ss : nullptr;
+    for (size_t s = 0; s < h->slabs.size(); ++s)
+        hipLaunchKernelGGL(k_interface, dim3(h->ifc_blocks * (256 / h->ifc_block)), dim3(h->ifc_block), 0, st, h->kp,
+                           view_of(h, (int)s), h->d_ktab, ss);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_sweep(Handle* h, bool batch, hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr, bool skip_ifc = false)
 {
     const int TR = SWEEP_TJ + 4;
     const size_t shmem0 = (size_t)((5 * TR * h->pitchS + 15) & ~15) + 225 * sizeof(double);
     const StepState* ss = batch ? h->d_ss : nullptr;
     const int njt = (h->L + SWEEP_TJ - 1) / SWEEP_TJ;
-    if (h->sweep_variant == 1) {
-        for (size_t s = 0; s < h->slabs.size(); ++s)
-            hipLaunchKernelGGL(k_interface, dim3(h->ifc_blocks * (256 / h->ifc_block)), dim3(h->ifc_block), 0, h->stream, h->kp, view_of(h, (int)s), h->d_ktab, ss);
-    }
+    if (h->sweep_variant == 1 && !skip_ifc) CHK(launch_interface(h, batch, h->stream));
     if (ev_a) HIPCHK(hipEventRecord(ev_a, h->stream));
     for (size_t s = 0; s < h->slabs.size(); ++s) {
         SlabView v = view_of(h, (int)s);
@@ -540,6 +552,9 @@ void destroy_impl(Handle* h)
     for (auto e : h->prof) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev_swept) (void)hipEventDestroy(h->ev_swept);
+    if (h->ev_ifc) (void)hipEventDestroy(h->ev_ifc);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -634,6 +649,7 @@ int cetkmc_set_option(void* handle, const char* key, int64_t value)
         h->swept = false;
         return 0;
     }
+    if (!strcmp(key, "overlap_interface")) { h->overlap_ifc = value ? 1 : 0; return 0; }
     if (!strcmp(key, "thermal_planes_per_block")) {
         if (value < 1 || value > 64) return fail("thermal_planes_per_block must be 1..64");
         h->therm_ni = (int)value;
@@ -793,8 +809,8 @@ int cetkmc_apply(void* handle, const cetkmc_event* ev, double theta_new, double 
     HIPCHK(hipSetDevice(h->dev));
     cetkmc_event e = *ev;
     if (e.type == CETKMC_DEP || e.type == CETKMC_NUC) { e.theta = theta_new; e.phi = phi_new; }
-    hipLaunchKernelGGL(k_apply_direct, dim3(1), dim3(64), 0, h->stream, (const SlabView*)h->d_views[h->cur],
-                       (int)h->slabs.size(), e, make_defect, h->d_ss);
+    hipLaunchKernelGGL(k_apply_direct, dim3(1), dim3(64), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
+                       (int)h->slabs.size(), e, make_defect, h->d_ss, (const double*)h->d_ktab);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     h->swept = false;
@@ -906,19 +922,33 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
     }
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     int64_t q_idx = 0;
+    bool ifc_fresh = false;     // ifc_val already holds this step's interface sums (speculative launch of the previous step)
     for (int64_t s = 0; s < n; ++s) {
         const int64_t g = a->step0 + s;
         if (a->thermal_mode && g % 20 == 0) {
             if (a->thermal_mode == 1) CHK(launch_thermal(h, a->thermal_dt, 0, nullptr, 0, 1, true));
             else { CHK(launch_thermal(h, a->thermal_dt, 1, h->d_q + (size_t)q_idx * L2, a->use_latent, 1, true)); ++q_idx; }
+            ifc_fresh = false;  // T changed
         }
-        if (a->profile) CHK(launch_sweep(h, true, h->prof[2 * s], h->prof[2 * s + 1]));
-        else CHK(launch_sweep(h, true));
+        if (a->profile) CHK(launch_sweep(h, true, h->prof[2 * s], h->prof[2 * s + 1], ifc_fresh));
+        else CHK(launch_sweep(h, true, nullptr, nullptr, ifc_fresh));
+        // Overlap: the interface sums of step s+1 are evaluated on a second stream while this step reduces
+        // and selects; the apply kernel then re-evaluates the <= 30 listed voxels the event touches, so
+        // every listed voxel is still evaluated in full for every step.  Not worth it before a thermal update.
+        const bool spec = h->overlap_ifc && h->sweep_variant == 1 && (s + 1 < n) && !(a->thermal_mode && (g + 1) % 20 == 0);
+        if (spec) {
+            HIPCHK(hipEventRecord(h->ev_swept, h->stream));
+            HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_swept, 0));
+            CHK(launch_interface(h, true, h->stream2));
+            HIPCHK(hipEventRecord(h->ev_ifc, h->stream2));
+        }
         CHK(launch_select(h, cfg, 0.0, 0));
+        if (spec) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ifc, 0));
         hipLaunchKernelGGL(k_apply_batch, dim3(1), dim3(64), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
                            (int)h->slabs.size(), h->L, (const cetkmc_event*)h->d_events_all, h->G, h->d_ss, cfg,
                            (const double*)h->d_u_defect, (const double*)h->d_u_np, h->d_log_total, h->d_log_event,
-                           h->d_log_nev);
+                           h->d_log_nev, (const double*)h->d_ktab, spec ? 1 : 0);
+        ifc_fresh = spec;
         h->swept = false;
     }
     HIPCHK(hipGetLastError());

@@ -579,9 +579,13 @@ __global__ void k_ifc_rebuild(SlabView S)
         if (is_interface(S, lp + 2, j, k)) ifc_append(S, lp, j, k);
     }
 }
-// after an event changed voxel (i,j,k): it and its 14 neighbours may have become interface
-// voxels.  Called by a full wave: lane l < 15 checks one of them.
-__device__ __forceinline__ void ifc_touch(const SlabView& S, int i, int j, int k, int lane)
+// after an event changed voxel (i,j,k): it and its 14 neighbours may have become interface voxels,
+// and the category sums of those already listed are stale (their neighbour states / orientations
+// changed).  Called by a full wave: lane l < 15 handles one of the 15 voxels: append if needed, then
+// re-evaluate if listed -- this keeps ifc_val/ifc_cnt exact when k_interface ran BEFORE the event
+// (the speculative, overlapped launch of the batched loop).
+__device__ __forceinline__ void ifc_touch(const KParams& P, const SlabView& S, const double* ktab, int i, int j, int k, int lane,
+                                          int eval)
 {
     if (lane >= 15) return;
     int ai = i, aj = j, ak = k;
@@ -590,7 +594,19 @@ __device__ __forceinline__ void ifc_touch(const SlabView& S, int i, int j, int k
     if (ai < 0 || ai >= L || aj < 0 || aj >= L || ak < 0 || ak >= L) return;
     const int lp = ai - S.gi0;
     if (lp < 0 || lp >= S.nloc) return;                      // owned planes only
-    if (is_interface(S, lp + 2, aj, ak)) ifc_append(S, lp, aj, ak);
+    const int li = lp + 2;
+    if (is_interface(S, li, aj, ak)) ifc_append(S, lp, aj, ak);
+    const int64_t t = S.tidx(li, aj, ak);
+    if (eval && S.ifc_in[t]) {
+        const int st = S.state[S.sidx(li, aj, ak)];
+        double sum = 0.0;
+        int cnt = 0;
+        auto nb = [&](int mm) -> int { return S.state[S.sidx(li + nbi_rt(mm), aj + nbj_rt(mm), ak + nbk_rt(mm))]; };
+        auto emit = [&](int cat, int, double rate, int, int) { if (cat != CAT_DEP) { sum += rate; ++cnt; } };
+        eval_voxel(P, S, ktab, li, ai, aj, ak, st, S.T[t], nb, emit);
+        S.ifc_val[t] = sum;
+        S.ifc_cnt[t] = (uint8_t)cnt;
+    }
 }
 // every step: EMPTY/DIFF category sum + count of every listed voxel, one voxel per lane.
 // Latency-bound gather kernel: all loads of a phase are issued together (own fields + 14
@@ -707,12 +723,14 @@ __device__ __forceinline__ void apply_event(const SlabView* slabs, int nslabs, c
 }
 
 // interface-list update for the voxels an event touched (all lanes of the first wave)
-__device__ __forceinline__ void apply_touch(const SlabView* slabs, int nslabs, const cetkmc_event& ev, int lane)
+__device__ __forceinline__ void apply_touch(const KParams& P, const SlabView* slabs, int nslabs, const double* ktab,
+                                            const cetkmc_event& ev, int lane, int eval)
 {
     for (int s = 0; s < nslabs; ++s) {
         const SlabView& S = slabs[s];
-        ifc_touch(S, ev.pos[0], ev.pos[1], ev.pos[2], lane);
-        if (ev.type == EV_DIFF) ifc_touch(S, ev.target[0], ev.target[1], ev.target[2], lane);
+        // lanes 0..14: neighbourhood of the event site; lanes 16..30: neighbourhood of a diffusion target
+        if (lane < 16) ifc_touch(P, S, ktab, ev.pos[0], ev.pos[1], ev.pos[2], lane, eval);
+        else if (ev.type == EV_DIFF) ifc_touch(P, S, ktab, ev.target[0], ev.target[1], ev.target[2], lane - 16, eval);
     }
 }
 
@@ -743,7 +761,8 @@ __global__ __launch_bounds__(64) void k_apply_batch(KParams P, const SlabView* _
                                                     const cetkmc_event* __restrict__ events_all, int G, StepState* ss,
                                                     BatchCfg cfg, const double* __restrict__ u_defect,
                                                     const double* __restrict__ u_np, double* log_total,
-                                                    cetkmc_event* log_event, int64_t* log_nev)
+                                                    cetkmc_event* log_event, int64_t* log_nev,
+                                                    const double* __restrict__ ktab_g, int eval_touched)
 {
     __shared__ cetkmc_event sh_ev;
     __shared__ int sh_ok;
@@ -784,19 +803,19 @@ __global__ __launch_bounds__(64) void k_apply_batch(KParams P, const SlabView* _
         }
     }
     __syncthreads();
-    if (sh_ok) apply_touch(slabs, nslabs, sh_ev, threadIdx.x);
+    if (sh_ok) apply_touch(P, slabs, nslabs, ktab_g, sh_ev, threadIdx.x, eval_touched);
 }
 
 // Direct apply (cetkmc_apply): everything decided by the host.  ONE 64-thread block.
-__global__ __launch_bounds__(64) void k_apply_direct(const SlabView* __restrict__ slabs, int nslabs, cetkmc_event ev,
-                                                     int make_defect, StepState* ss)
+__global__ __launch_bounds__(64) void k_apply_direct(KParams P, const SlabView* __restrict__ slabs, int nslabs, cetkmc_event ev,
+                                                     int make_defect, StepState* ss, const double* __restrict__ ktab_g)
 {
     if (threadIdx.x == 0) {
         if (ev.type == EV_NUC) ss->nuc_count += 1;
         apply_event(slabs, nslabs, ev, make_defect);
     }
     __syncthreads();
-    apply_touch(slabs, nslabs, ev, threadIdx.x);
+    apply_touch(P, slabs, nslabs, ktab_g, ev, threadIdx.x, 0);
 }
 
 // ---- thermal -------------------------------------------------------------------------------

@@ -403,3 +403,52 @@ def test_thermal_kernel_variants_identical(L, n_slabs):
         outs.append((a, b, e.download()["T"]))
     for x, y in zip(*outs):
         assert np.array_equal(x, y)
+
+
+def test_large_L_two_chunks_per_row():
+    """L > 256: rows span two 256-voxel chunks in the streaming kernel (the N=2/4/8 bench sizes 320/408/512
+    take this path).  Streaming == simple kernel bit for bit, slab-count invariant, incl. after stepping."""
+    import cetkmc
+    from cetkmc import synthetic
+    L = 264
+    st, th, ph, T, df = synthetic.planes(L, 0, L, seed=3)
+    rs = np.random.RandomState(9)
+    # sprinkle isolated atoms / defects into the empty region so every event family occurs there too
+    idx = rs.randint(0, L, (4000, 3))
+    st[idx[:, 0], idx[:, 1], idx[:, 2]] = rs.randint(1, 5, 4000)
+    n = 10
+    q = synthetic.laser_planes(L, 0, n)
+    u_pick, u_def, u_np = rs.random_sample(n), rs.random_sample(n), rs.random_sample(2 * n + 2)
+    outs = []
+    for ns, variant in ((1, 1), (1, 0), (3, 1)):
+        e = cetkmc.Engine(L, impurity_c=0.2, n_slabs=ns)
+        e.set_option("sweep_variant", variant)
+        e.upload_planes(0, L, st, th, ph, T, df)
+        e.set_prev_state(None)
+        info = e.rate_sweep()
+        rsum, rcnt = e.row_sums()
+        r = e.run_steps(0, n, 3e-3, u_pick, u_def, u_np, rng_mode=1, seed=5, thermal_mode=2, q_planes=q)
+        assert r["done"] == n
+        outs.append((info, rsum.tobytes(), rcnt.tobytes(), r["totals"].tobytes(), r["events"].tobytes()))
+        e.close()
+    assert outs[0] == outs[1] and outs[0] == outs[2]
+
+
+def test_overlapped_interface_option_identical():
+    """overlap_interface=1 (speculative k_interface on a second stream + re-evaluation of the touched
+    voxels inside the apply kernel) must not change a single bit."""
+    L = 40
+    state, theta, phi, T, defects = random_lattice(L, 31, fill=0.2)
+    rs = np.random.RandomState(8)
+    n = 70
+    u_pick, u_def, u_np = rs.random_sample(n), rs.random_sample(n), rs.random_sample(n * (L * L + 2))
+    outs = []
+    for ov in (0, 1):
+        e = _engine(L, 0.2)
+        e.set_option("overlap_interface", ov)
+        e.upload(state, theta, phi, T, defects)
+        res = e.run_steps(0, n, 0.05, u_pick, u_def, u_np, rng_mode=0, thermal_mode=1)
+        assert res["done"] == n
+        info = e.rate_sweep()
+        outs.append((res["totals"].tobytes(), res["events"].tobytes(), info, e.row_sums()[0].tobytes(), e.download()["theta"].tobytes()))
+    assert outs[0] == outs[1]
