@@ -341,7 +341,10 @@ __global__ __launch_bounds__(256) void k_sweep_stream(StreamArgs A, const double
                 }
             }
             // ---- row totals: balanced tree over the chunk partials; counts reduced once ------------
-            const int n0 = wave_sum_i(cdep), n1 = wave_sum_i(cdiff), n2 = wave_sum_i(cemp);
+            // per-lane counts are <= 4*nch*15 < 2^10 each, so diff and empty share one integer butterfly
+            const int packed = wave_sum_i(cemp | (cdiff << 16));
+            const int n2 = packed & 0xFFFF, n1 = packed >> 16;
+            const int n0 = top ? wave_sum_i(cdep) : 0;
             if (lane == 0 && j < L) {
                 const int64_t o = (int64_t)lp * 3 * L + j;
 #pragma unroll
