@@ -245,6 +245,8 @@ int create_common(const cetkmc_params* p, int L, const std::vector<std::pair<int
         HIPCHK(hipMalloc((void**)&s.v.ifc_val, s.nT * sizeof(double)));
         HIPCHK(hipMalloc((void**)&s.v.ifc_cnt, s.nT));
         HIPCHK(hipMalloc((void**)&s.v.ifc_in, s.nT));
+        HIPCHK(hipMalloc((void**)&s.v.ifc_code, s.nT * sizeof(uint32_t)));
+        HIPCHK(hipMemsetAsync(s.v.ifc_code, 0xFF, s.nT * sizeof(uint32_t), h->stream));
         HIPCHK(hipMalloc((void**)&s.v.ifc_list, (size_t)r.second * L * L * sizeof(uint32_t)));
         HIPCHK(hipMalloc((void**)&s.v.ifc_n, sizeof(int)));
         HIPCHK(hipMemsetAsync(s.v.ifc_val, 0, s.nT * sizeof(double), h->stream));
@@ -543,7 +545,7 @@ void destroy_impl(Handle* h)
         (void)hipFree(s.v.state); (void)hipFree(s.v.defects); (void)hipFree(s.prev); (void)hipFree(s.v.cls);
         (void)hipFree(s.Tbuf[0]); (void)hipFree(s.Tbuf[1]); (void)hipFree(s.v.theta); (void)hipFree(s.v.phi); (void)hipFree(s.v.ovec);
         (void)hipFree(s.v.rowsum); (void)hipFree(s.v.rowcnt);
-        (void)hipFree(s.v.ifc_val); (void)hipFree(s.v.ifc_cnt); (void)hipFree(s.v.ifc_in); (void)hipFree(s.v.ifc_list); (void)hipFree(s.v.ifc_n);
+        (void)hipFree(s.v.ifc_val); (void)hipFree(s.v.ifc_cnt); (void)hipFree(s.v.ifc_in); (void)hipFree(s.v.ifc_code); (void)hipFree(s.v.ifc_list); (void)hipFree(s.v.ifc_n);
     }
     void* ptrs[] = {h->d_views[0], h->d_views[1], h->d_blocks, h->d_events_all, h->d_ss, h->d_ktab, h->d_kp, h->d_scratch,
                     h->d_flag, h->d_qtop, h->d_u_pick, h->d_u_defect, h->d_u_np, h->d_q, h->d_log_total,

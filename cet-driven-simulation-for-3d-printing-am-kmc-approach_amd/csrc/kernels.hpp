@@ -550,17 +550,30 @@ __global__ __launch_bounds__(256) void k_select(KParams P, const SlabView* __res
 // expensive, so they are kept in a per-slab list (append-only superset, rebuilt at upload),
 // evaluated one voxel per lane by k_interface into ifc_val/ifc_cnt every step, and merely
 // looked up by the streaming sweep kernel.
-__device__ __forceinline__ bool is_interface(const SlabView& S, int li, int j, int k)
+// Packed neighbourhood of a voxel: bits [2m+1:2m] describe neighbour slot m, bits [29:28] the voxel.
+//   empty voxel (own = 0): slot = species of a W/Re/C neighbour (1,2,3), 0 otherwise
+//   atom voxel  (own = 1,2,3 = species): slot = 1 empty, 2 occupied (any non-empty in-lattice state), 0 outside
+// k_interface evaluates a listed voxel from this word alone (no neighbour-state gathers).
+__device__ __forceinline__ unsigned ifc_encode(const SlabView& S, int li, int j, int k, bool* interface_out)
 {
     const int st = S.state[S.sidx(li, j, k)];
-    if (st >= 128 || st == 4) return false;
+    unsigned code = 0;
     bool hit = false;
+    if (st < 128 && st != 4) {
+        code = (unsigned)(st & 3) << 28;
 #pragma unroll
-    for (int m = 0; m < 14; ++m) {          // unrolled: the 14 loads are issued together
-        const int sm = S.state[S.sidx(li + nbi_rt(m), j + nbj_rt(m), k + nbk_rt(m))];
-        hit |= (st == 0) ? (sm >= 1 && sm <= 3) : (sm == 0);
+        for (int m = 0; m < 14; ++m) {          // unrolled: the 14 loads are issued together
+            const int sm = S.state[S.sidx(li + nbi_rt(m), j + nbj_rt(m), k + nbk_rt(m))];
+            unsigned c;
+            if (st == 0) { c = (sm >= 1 && sm <= 3) ? (unsigned)sm : 0u; hit |= (c != 0u); }
+            else { c = (sm == 0) ? 1u : ((sm != OOB) ? 2u : 0u); hit |= (sm == 0); }
+            code |= c << (2 * m);
+        }
+    } else {
+        code = 3u << 30;                        // defect / outside: no events
     }
-    return hit;
+    *interface_out = hit;
+    return code;
 }
 __device__ __forceinline__ void ifc_append(const SlabView& S, int lp, int j, int k)
 {
@@ -579,7 +592,9 @@ __global__ void k_ifc_rebuild(SlabView S)
         const int k = (int)(idx % L);
         const int64_t t = idx / L;
         const int j = (int)(t % L), lp = (int)(t / L);
-        if (is_interface(S, lp + 2, j, k)) ifc_append(S, lp, j, k);
+        bool hit;
+        const unsigned code = ifc_encode(S, lp + 2, j, k, &hit);
+        if (hit) { ifc_append(S, lp, j, k); S.ifc_code[S.tidx(lp + 2, j, k)] = code; }
     }
 }
 // after an event changed voxel (i,j,k): it and its 14 neighbours may have become interface voxels,
@@ -598,8 +613,11 @@ __device__ __forceinline__ void ifc_touch(const KParams& P, const SlabView& S, c
     const int lp = ai - S.gi0;
     if (lp < 0 || lp >= S.nloc) return;                      // owned planes only
     const int li = lp + 2;
-    if (is_interface(S, li, aj, ak)) ifc_append(S, lp, aj, ak);
+    bool hit;
+    const unsigned code = ifc_encode(S, li, aj, ak, &hit);
+    if (hit) ifc_append(S, lp, aj, ak);
     const int64_t t = S.tidx(li, aj, ak);
+    if (S.ifc_in[t]) S.ifc_code[t] = code;
     if (eval && S.ifc_in[t]) {
         const int st = S.state[S.sidx(li, aj, ak)];
         double sum = 0.0;
@@ -628,27 +646,31 @@ __global__ __launch_bounds__(256) void k_interface(KParams P, SlabView S, const 
         const int lp = v >> 20, j = (v >> 10) & 1023, k = v & 1023;
         const int li = lp + 2;
         const int64_t t = S.tidx(li, j, k);
-        const int st = S.state[S.sidx(li, j, k)];
+        const unsigned code = S.ifc_code[t];
+        const int st = (code >> 30) ? 4 : (int)((code >> 28) & 3u);     // 4: no events
         const double Tc = pymax(S.T[t], 1.0);
-        int s[14];
-#pragma unroll
-        for (int m = 0; m < 14; ++m) s[m] = S.state[S.sidx(li + nbi_rt(m), j + nbj_rt(m), k + nbk_rt(m))];
         double sum = 0.0;
         int cnt = 0;
         if (st == 0) {
-            int n_nb = 0, n_imp = 0, n_src = 0;
+            // in-lattice neighbour count from the coordinates (kmc_event_rates.py:32,37)
+            const int i = S.gi0 + lp, L = S.L;
+            int n_nb = 0, n_imp = 0;
+            unsigned mask = 0;
 #pragma unroll
-            for (int m = 0; m < 14; ++m) { n_nb += (s[m] != OOB); n_imp += (s[m] == 2 || s[m] == 3); n_src += (s[m] >= 1 && s[m] <= 3); }
+            for (int m = 0; m < 14; ++m) {
+                const int ni = i + nbi_rt(m), nj = j + nbj_rt(m), nk = k + nbk_rt(m);
+                n_nb += (ni >= 0 && ni < L && nj >= 0 && nj < L && nk >= 0 && nk < L);
+                const unsigned c = (code >> (2 * m)) & 3u;
+                n_imp += (c >= 2u);
+                if (c) mask |= 1u << m;
+            }
             const double dT = P.T_melt - Tc;
             if (dT > P.delta_T_c) {
                 const double rate = nuc_rate(P, ktab[n_nb * 15 + n_imp], dT, P.kT * Tc);
                 if (rate > P.rate_threshold && finite_d(rate)) { sum = rate; cnt = 1; }
             }
-            if (n_src > 0) {
+            if (mask) {
                 const AttCtx c = att_ctx(P, S, li, j, k, Tc);
-                unsigned mask = 0;
-#pragma unroll
-                for (int m = 0; m < 14; ++m) if (s[m] >= 1 && s[m] <= 3) mask |= 1u << m;
                 while (mask) {                                   // batches of 4 attachment sources
                     int ms[4];
                     double b[4][3];
@@ -663,20 +685,22 @@ __global__ __launch_bounds__(256) void k_interface(KParams P, SlabView S, const 
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         if (ms[u] >= 0) {
-                            int sn = 0;
-#pragma unroll
-                            for (int m = 0; m < 14; ++m) if (m == ms[u]) sn = s[m];
+                            const int sn = (int)((code >> (2 * ms[u])) & 3u);
                             const double rate = att_item(P, c, b[u][0], b[u][1], b[u][2], sn);
                             if (rate > P.rate_threshold && finite_d(rate)) { sum = sum + rate; ++cnt; }
                         }
                     }
                 }
             }
-        } else if (st != 4 && st < 128) {
+        } else if (st != 4) {
             int n_bonds = 0;
             unsigned mask = 0;
 #pragma unroll
-            for (int m = 0; m < 14; ++m) { n_bonds += (s[m] != 0 && s[m] != OOB); if (s[m] == 0) mask |= 1u << m; }
+            for (int m = 0; m < 14; ++m) {
+                const unsigned c = (code >> (2 * m)) & 3u;
+                n_bonds += (c == 2u);
+                if (c == 1u) mask |= 1u << m;
+            }
             if (mask) {
                 const DiffCtx c = diff_ctx(P, S, li, j, k, st, n_bonds, Tc);
                 double Tn[14];

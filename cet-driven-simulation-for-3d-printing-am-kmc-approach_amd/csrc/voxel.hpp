@@ -67,6 +67,7 @@ struct SlabView {
     double* ifc_val;    // [(nloc+4)][L][pitchT] EMPTY- or DIFF-category sum of an interface voxel (tidx)
     uint8_t* ifc_cnt;   // same indexing: its event count
     uint8_t* ifc_in;    // same indexing: 1 if the voxel is in ifc_list
+    uint32_t* ifc_code; // same indexing: packed neighbourhood of a listed voxel (ifc_encode), kept current by apply
     uint32_t* ifc_list; // packed (lp << 20 | j << 10 | k) of the listed voxels (append-only, superset)
     int* ifc_n;         // number of listed voxels
     __device__ __forceinline__ int64_t sidx(int li, int j, int k) const {
