@@ -125,6 +125,7 @@ struct Handle {
     int ifc_blocks = 64;       // grid of k_interface (grid-stride over the device-side list length)
     int ifc_block = 256;
     size_t shmem_stream = 0;
+    int stream_tj = SWEEP_TJ;  // rows per block of the streaming sweep: 8, or 4 when the 8-row LDS ring would exceed ~40 KB
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> prof;
 };
@@ -205,9 +206,13 @@ int create_common(const cetkmc_params* p, int L, const std::vector<std::pair<int
     if (const char* e = getenv("CETKMC_TPAD")) h->pitchT += 2 * atoi(e);   // experiment: row padding (doubles/2)
     if (const char* e = getenv("CETKMC_IFC_BLOCK")) h->ifc_block = atoi(e);
     h->pitchC = round_up(KOFFC + L + 8, 8);
-    h->shmem_stream = (size_t)((5 * (SWEEP_TJ + 4) * h->pitchC * 2 + 15) & ~15) + (226 + SWEEP_TJ * 3 * STREAM_MAXCH) * sizeof(double);
+    auto stream_lds = [&](int tj) { return (size_t)((5 * (tj + 4) * h->pitchC * 2 + 15) & ~15) + (226 + tj * 3 * STREAM_MAXCH) * sizeof(double); };
+    h->stream_tj = (stream_lds(8) <= 40 * 1024) ? 8 : 4;
+    if (const char* e = getenv("CETKMC_STREAM_TJ")) h->stream_tj = (atoi(e) == 4) ? 4 : 8;
+    h->shmem_stream = stream_lds(h->stream_tj);
     if (h->shmem_stream > 160 * 1024) { delete h; return fail("L too large for the LDS ring"); }
-    HIPCHK(hipFuncSetAttribute((const void*)k_sweep_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->shmem_stream));
+    HIPCHK(hipFuncSetAttribute((const void*)k_sweep_stream<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds(8)));
+    HIPCHK(hipFuncSetAttribute((const void*)k_sweep_stream<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds(4)));
     h->dev = dev; h->G = G; h->my_first = my_first;
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
@@ -432,7 +437,11 @@ int launch_sweep(Handle* h, bool batch, hipEvent_t ev_a = nullptr, hipEvent_t ev
             sa.cls = v.cls; sa.T = v.T; sa.ifc_val = v.ifc_val; sa.ifc_cnt = v.ifc_cnt; sa.rowsum = v.rowsum; sa.rowcnt = v.rowcnt;
             const int nib = (v.nloc + STREAM_NI - 1) / STREAM_NI;
             sa.group_first = 0; sa.group_count = nib;
-            hipLaunchKernelGGL(k_sweep_stream, dim3(nib * njt), dim3(256), h->shmem_stream, h->stream, sa, h->d_ktab, ss);
+            if (h->stream_tj == 8) {
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_stream<8>), dim3(nib * ((h->L + 7) / 8)), dim3(256), h->shmem_stream, h->stream, sa, h->d_ktab, ss);
+            } else {
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_stream<4>), dim3(nib * ((h->L + 3) / 4)), dim3(256), h->shmem_stream, h->stream, sa, h->d_ktab, ss);
+            }
         } else {
             hipLaunchKernelGGL(k_sweep_simple, dim3(v.nloc * njt), dim3(256), shmem0, h->stream, h->kp, v, h->d_ktab, ss);
         }

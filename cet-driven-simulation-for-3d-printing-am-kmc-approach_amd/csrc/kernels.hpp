@@ -216,12 +216,13 @@ struct StreamArgs {
 
 __device__ __forceinline__ unsigned alignbit16(unsigned hi, unsigned lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
 
+template <int TJ>
 __global__ __launch_bounds__(256) void k_sweep_stream(StreamArgs A, const double* __restrict__ ktab_g,
                                                       const StepState* __restrict__ ss)
 {
     if (ss && ss->status) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int TJ = SWEEP_TJ, TR = TJ + 4;
+    constexpr int TR = TJ + 4;          // TJ = rows per block: 8 (two per wave) or 4 (one per wave, smaller ring for large L)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int L = A.L;
     const int njt = (L + TJ - 1) / TJ;
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(256) void k_sweep_stream(StreamArgs A, const double
 #pragma unroll
         for (int d = 0; d < 5; ++d) so[d] = ((li - 2 + d) % 5) * slab;
 #pragma unroll 1
-        for (int rr = 0; rr < 2; ++rr) {
+        for (int rr = 0; rr < TJ / 4; ++rr) {
             const int r = w + 4 * rr, j = j0 + r;
             int cdep = 0, cdiff = 0, cemp = 0;
 #pragma unroll 1

@@ -452,3 +452,20 @@ def test_overlapped_interface_option_identical():
         info = e.rate_sweep()
         outs.append((res["totals"].tobytes(), res["events"].tobytes(), info, e.row_sums()[0].tobytes(), e.download()["theta"].tobytes()))
     assert outs[0] == outs[1]
+
+
+@pytest.mark.parametrize("L", [36, 264])
+def test_stream_kernel_four_row_blocks(L, monkeypatch):
+    """The 4-rows-per-block instantiation of the streaming kernel (picked automatically for L >= ~300,
+    i.e. the multi-GPU bench sizes) equals the simple kernel bit for bit."""
+    import cetkmc
+    monkeypatch.setenv("CETKMC_STREAM_TJ", "4")
+    state, theta, phi, T, defects = random_lattice(L, 77, fill=0.15 if L < 100 else 0.02)
+    e = cetkmc.Engine(L, impurity_c=0.2)
+    e.upload(state, theta, phi, T, defects)
+    out = []
+    for v in (1, 0):
+        e.set_option("sweep_variant", v)
+        out.append((e.rate_sweep(),) + e.row_sums())
+    assert out[0][0] == out[1][0]
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
