@@ -31,7 +31,7 @@ summary = {"tag": tag, "kernels": {}}
 if stats:
     shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
     for r in csv.DictReader(open(stats)):
-        name = r["Name"].split("(")[0].replace("cetkmc::", "").replace("void ", "")
+        name = r["Name"].split("(")[0].replace("cetkmc::", "").replace("void ", "").split("<")[0]
         summary["kernels"][name] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
                                     "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3,
                                     "pct": float(r["Percentage"])}
@@ -41,13 +41,13 @@ for which in ("fetch", "write"):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        name = r["Kernel_Name"].split("(")[0].replace("cetkmc::", "").replace("void ", "")
+        name = r["Kernel_Name"].split("(")[0].replace("cetkmc::", "").replace("void ", "").split("<")[0]
         agg[name].append(float(r["Counter_Value"]))
     for name, v in agg.items():
         summary["kernels"].setdefault(name, {})[f"{which}_size_kb_median"] = statistics.median(v)
 for name, k in summary["kernels"].items():
     if "fetch_size_kb_median" in k and "write_size_kb_median" in k:
-        wide = name in ("k_sweep_stream", "k_thermal")
+        wide = name in ("k_sweep_stream", "k_thermal", "k_thermal_march")
         k["hbm_bytes_per_launch"] = (2.0 if wide else 1.0) * k["fetch_size_kb_median"] * 1024 + k["write_size_kb_median"] * 1024
         k["fetch_x2_applied"] = wide
 for f in (f"{tag}_bench.json", f"{tag}_bench_under_rocprof.json"):
