@@ -74,6 +74,35 @@ def _advance_to(engine, first, last, L, defect_fraction, rng_mode=0, seed=0):
     return step - first, terminated, last_total, dts
 
 
+def save_checkpoint(path, fields, defects_mask, next_step, total_time, nucleation_count, metrics_data, cet_detected):
+    """Everything needed to continue a run bit-identically: the five lattice fields, the defect mask,
+    the loop counters, the metrics rows so far and the state of BOTH host generators (CPython
+    ``random`` and NumPy's legacy global stream).  The reference has no resume."""
+    import json
+    py = random.getstate()
+    npst = np.random.get_state()
+    np.savez_compressed(
+        path, state=fields["state"].astype(np.int8), theta=fields["theta"], phi=fields["phi"], T=fields["T"],
+        defects=np.asarray(defects_mask).astype(np.int8), next_step=next_step, total_time=total_time,
+        nucleation_count=nucleation_count, cet_detected=bool(cet_detected),
+        py_version=py[0], py_mt=np.array(py[1], dtype=np.uint64), py_gauss=np.array([np.nan if py[2] is None else py[2]]),
+        np_mt=npst[1], np_pos=npst[2], np_has_gauss=npst[3], np_cached=npst[4],
+        metrics_json=np.array(json.dumps(metrics_data, default=lambda o: o.item() if hasattr(o, "item") else str(o))))
+
+
+def load_checkpoint(path):
+    """Inverse of save_checkpoint; also restores both host generators."""
+    import json
+    z = np.load(path, allow_pickle=False)
+    g = float(z["py_gauss"][0])
+    random.setstate((int(z["py_version"]), tuple(int(x) for x in z["py_mt"]), None if np.isnan(g) else g))
+    np.random.set_state(("MT19937", z["np_mt"], int(z["np_pos"]), int(z["np_has_gauss"]), float(z["np_cached"])))
+    return dict(state=z["state"].astype(np.int64), theta=z["theta"], phi=z["phi"], T=z["T"],
+                defects=z["defects"].astype(np.int64), next_step=int(z["next_step"]), total_time=float(z["total_time"]),
+                nucleation_count=int(z["nucleation_count"]), cet_detected=bool(z["cet_detected"]),
+                metrics_data=json.loads(str(z["metrics_json"])))
+
+
 def run_kmc(
     L: int = LATTICE_SIZE,
     n_steps: int = N_STEPS,
@@ -82,21 +111,33 @@ def run_kmc(
     n_seeds: int = 5,
     impurity_c: float = 0.0,
     output_prefix: str = "cet_run",
+    *,
+    checkpoint_every: int = 0,
+    resume_from: str = None,
 ):
     """KMC microstructure evolution with natural defect injection (same contract as the
     reference).  ``defect_fraction`` is the per-event probability that the just-updated voxel
-    becomes a defect."""
-    import cetkmc
+    becomes a defect.
 
-    np.random.seed(RANDOM_SEED)
-    random.seed(RANDOM_SEED)
+    Extensions (keyword-only, not in the reference): ``checkpoint_every=k`` writes
+    ``outputs/<prefix>/checkpoint.npz`` every k steps; ``resume_from=path`` continues such a run --
+    the continued run is bit-identical to an uninterrupted one (lattice, time, CSV, RNG streams)."""
+    import cetkmc
 
     output_dir = f"outputs/{output_prefix}"
     os.makedirs(output_dir, exist_ok=True)
-
-    state, theta, phi, T, atom_type = initialize_lattice(
-        lattice_size=L, n_seeds=n_seeds, T_sub=temp, impurity_c=impurity_c)
-    defects_mask, defect_density = introduce_defects(state, atom_type, T, apply_to_state=False)
+    ckpt = None
+    if resume_from:
+        ckpt = load_checkpoint(resume_from)
+        state, theta, phi, T = ckpt["state"], ckpt["theta"], ckpt["phi"], ckpt["T"]
+        atom_type = state.copy()
+        defects_mask = ckpt["defects"]
+    else:
+        np.random.seed(RANDOM_SEED)
+        random.seed(RANDOM_SEED)
+        state, theta, phi, T, atom_type = initialize_lattice(
+            lattice_size=L, n_seeds=n_seeds, T_sub=temp, impurity_c=impurity_c)
+        defects_mask, defect_density = introduce_defects(state, atom_type, T, apply_to_state=False)
 
     G = (T_MELT - T_SUB) / (L * VOXEL_SIZE)
     R = NU_DEP * 2.74e-10 / VOXEL_SIZE
@@ -111,12 +152,19 @@ def run_kmc(
     cet_detected = False
     step = -1
     next_step = 0
+    nuc_offset = 0
+    if ckpt:
+        total_time, metrics_data, cet_detected = ckpt["total_time"], ckpt["metrics_data"], ckpt["cet_detected"]
+        next_step, nuc_offset = ckpt["next_step"], ckpt["nucleation_count"]
+        step = next_step - 1
     while next_step < n_steps:
         # next step after which the host has work: metrics (and, on multiples of
         # METRIC_UPDATE_STEP, the defect-mask refresh) -- kmc_simulation.py:335-341
         stop = next_step if next_step % METRIC_UPDATE_STEP == 0 else \
             min((next_step // METRIC_UPDATE_STEP + 1) * METRIC_UPDATE_STEP, n_steps - 1)
         stop = min(stop, n_steps - 1)
+        if checkpoint_every > 0:      # also stop right before every checkpoint boundary
+            stop = min(stop, (next_step // checkpoint_every + 1) * checkpoint_every - 1)
         done, terminated, last_total, dts = _advance_to(engine, next_step, stop, L, defect_fraction)
         for dt in dts:
             total_time += dt
@@ -130,6 +178,11 @@ def run_kmc(
         fields = engine.download()
         state, theta, phi, T = fields["state"], fields["theta"], fields["phi"], fields["T"]
         atom_type = state.copy()
+        is_metric_step = (step % METRIC_UPDATE_STEP == 0) or (step == n_steps - 1)
+        if not is_metric_step:        # a pure checkpoint stop
+            save_checkpoint(os.path.join(output_dir, "checkpoint.npz"), fields, defects_mask, next_step, total_time,
+                            nuc_offset + engine.nucleation_count(), metrics_data, cet_detected)
+            continue
         if step % METRIC_UPDATE_STEP == 0:
             defects_mask, defect_density = introduce_defects(state, atom_type, T, apply_to_state=False)
             engine.set_defects(defects_mask)
@@ -153,7 +206,7 @@ def run_kmc(
             "W_Count": int((state == 1).sum()),
             "Re_Count": int((state == 2).sum()),
             "C_Count": int((state == 3).sum()),
-            "NucleationCount": engine.nucleation_count(),
+            "NucleationCount": nuc_offset + engine.nucleation_count(),
             "G_over_R": (G / R) if R > 0 else np.inf,
             "G_phys": G,
             "R_phys": R_phys,
@@ -171,6 +224,9 @@ def run_kmc(
             f"Detected={row['CET_Detected']}, "
             f"Time={row['Time']:.2e}s"
         )
+        if checkpoint_every > 0 and next_step % checkpoint_every == 0:
+            save_checkpoint(os.path.join(output_dir, "checkpoint.npz"), fields, defects_mask, next_step, total_time,
+                            nuc_offset + engine.nucleation_count(), metrics_data, cet_detected)
 
     if metrics_data:
         df = pd.DataFrame(metrics_data)

@@ -127,3 +127,23 @@ def test_rccl_single_rank_mode():
     assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
     for k in outs[0][2]:
         assert np.array_equal(outs[0][2][k], outs[1][2][k])
+
+
+def test_checkpoint_resume_is_bit_identical(tmp_path, monkeypatch):
+    """a run interrupted at a checkpoint and resumed equals the uninterrupted run
+    (lattice, orientations, time, metrics rows, both RNG streams)."""
+    import kmc_simulation
+    monkeypatch.chdir(tmp_path)
+    kw = dict(L=10, temp=2800, defect_fraction=0.01, n_seeds=6, impurity_c=0.2)
+    full = kmc_simulation.run_kmc(n_steps=450, output_prefix="full", **kw)
+    py_end, np_end = random.random(), np.random.random()
+    kmc_simulation.run_kmc(n_steps=131, output_prefix="part", checkpoint_every=130, **kw)   # leaves the checkpoint of step 130
+    part = kmc_simulation.run_kmc(n_steps=450, output_prefix="part", resume_from="outputs/part/checkpoint.npz", **kw)
+    assert (random.random(), np.random.random()) == (py_end, np_end)
+    for a, b in zip(full, part):
+        assert np.array_equal(a, b)
+    z = load("traj_L10_n450")
+    assert np.array_equal(part[0], z["final_state"]) and part[2] == float(z["total_time"])
+    a = pd.read_csv("outputs/full/metrics.csv")
+    b = pd.read_csv("outputs/part/metrics.csv")
+    assert a.equals(b)
