@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 INCLUDE = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include")
 SO_PATH = os.path.join(CSRC, "libcetkmc_hip.so")
-SOURCES = [os.path.join(CSRC, f) for f in ("cetkmc_hip.hip", "kernels.hpp", "voxel.hpp")] + [os.path.join(INCLUDE, "cetkmc.h")]
+SOURCES = [os.path.join(CSRC, f) for f in ("cetkmc_hip.hip", "kernels.hpp", "voxel.hpp", "cluster.hpp")] + [os.path.join(INCLUDE, "cetkmc.h")]
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                "-fno-fast-math", "-I/opt/rocm/include"]
@@ -80,6 +80,12 @@ PROTOTYPES = {
     "cetkmc_enumerate_events": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _P(C.c_int64)]),
     "cetkmc_row_sums": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cetkmc_run_steps": (C.c_int, [C.c_void_p, _P(RunArgs), _P(RunResult), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cetkmc_cluster": (C.c_int, [C.c_void_p, C.c_double, _P(C.c_int64)]),
+    "cetkmc_cluster_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cetkmc_cluster_labels": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cetkmc_species_counts": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cetkmc_gather_species": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, _P(C.c_int64)]),
+    "cetkmc_set_defects_sparse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "cetkmc_nucleation_count": (C.c_int64, [C.c_void_p]),
     "cetkmc_reset_counters": (C.c_int, [C.c_void_p]),
     "cetkmc_time_sweeps": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_double)]),

@@ -252,6 +252,47 @@ class Engine:
             out.update(totals=totals[:done + (1 if res.status == 1 else 0)], events=events[:done], n_events=nev[:done])
         return out
 
+    # -- grain clustering (utils.get_clusters on the device) --------------------------------------
+    def clusters(self, threshold=0.5, labels=False):
+        """dict(first (n,3) int32, size (n,) int64, bbox (n,6) int32[, labels (L,L,L) int32]); clusters are
+        numbered in the reference's order (first voxel, row-major)."""
+        n = C.c_int64(0)
+        self._ck(self.lib.cetkmc_cluster(self.h, float(threshold), C.byref(n)))
+        k = n.value
+        first = np.zeros((max(k, 1), 3), np.int32)
+        size = np.zeros(max(k, 1), np.int64)
+        bbox = np.zeros((max(k, 1), 6), np.int32)
+        if k:
+            self._ck(self.lib.cetkmc_cluster_stats(self.h, k, _ptr(first), _ptr(size), _ptr(bbox)))
+        out = dict(first=first[:k], size=size[:k], bbox=bbox[:k])
+        if labels:
+            lab = np.zeros((self.L,) * 3, np.int32)
+            self._ck(self.lib.cetkmc_cluster_labels(self.h, _ptr(lab)))
+            out["labels"] = lab
+        return out
+
+    # -- sparse site queries (defect model / species counts without full-lattice transfers) -------
+    def species_counts(self):
+        c = np.zeros(6, np.int64)
+        self._ck(self.lib.cetkmc_species_counts(self.h, _ptr(c)))
+        return c
+
+    def gather_species(self, species):
+        """(linear indices ascending, T at those voxels) of the owned voxels in state ``species``."""
+        n = C.c_int64(0)
+        self._ck(self.lib.cetkmc_gather_species(self.h, int(species), None, None, 0, C.byref(n)))
+        k = n.value
+        idx = np.zeros(max(k, 1), np.int64)
+        Tv = np.zeros(max(k, 1), np.float64)
+        if k:
+            self._ck(self.lib.cetkmc_gather_species(self.h, int(species), _ptr(idx), _ptr(Tv), k, C.byref(n)))
+        order = np.argsort(idx[:k], kind="stable")
+        return idx[:k][order], Tv[:k][order]
+
+    def set_defects_sparse(self, lin_idx):
+        a = np.ascontiguousarray(lin_idx, dtype=np.int64)
+        self._ck(self.lib.cetkmc_set_defects_sparse(self.h, _ptr(a) if len(a) else None, len(a)))
+
     def nucleation_count(self):
         return int(self.lib.cetkmc_nucleation_count(self.h))
 

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "cluster.hpp"
 
 using namespace cetkmc;
 
@@ -127,6 +128,10 @@ struct Handle {
     size_t shmem_stream = 0;
     int stream_tj = SWEEP_TJ;  // rows per block of the streaming sweep: 8, or 4 when the 8-row LDS ring would exceed ~40 KB
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // grain clustering (cetkmc_cluster): results kept until the next call
+    int *d_cc_parent = nullptr, *d_cc_roots = nullptr, *d_cc_cid = nullptr, *d_cc_labels = nullptr, *d_cc_stats = nullptr, *d_cc_n = nullptr;
+    int64_t cc_n_clusters = -1;
+    std::vector<int> cc_roots_sorted;
     std::vector<hipEvent_t> prof;
 };
 
@@ -556,6 +561,8 @@ void destroy_impl(Handle* h)
         (void)hipFree(s.v.rowsum); (void)hipFree(s.v.rowcnt);
         (void)hipFree(s.v.ifc_val); (void)hipFree(s.v.ifc_cnt); (void)hipFree(s.v.ifc_in); (void)hipFree(s.v.ifc_code); (void)hipFree(s.v.ifc_list); (void)hipFree(s.v.ifc_n);
     }
+    void* ccp[] = {h->d_cc_parent, h->d_cc_roots, h->d_cc_cid, h->d_cc_labels, h->d_cc_stats, h->d_cc_n};
+    for (void* p : ccp) if (p) (void)hipFree(p);
     void* ptrs[] = {h->d_views[0], h->d_views[1], h->d_blocks, h->d_events_all, h->d_ss, h->d_ktab, h->d_kp, h->d_scratch,
                     h->d_flag, h->d_qtop, h->d_u_pick, h->d_u_defect, h->d_u_np, h->d_q, h->d_log_total,
                     h->d_log_event, h->d_log_nev};
@@ -986,6 +993,150 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
     if (totals && ss.status == 1 && nt <= n) totals[done] = ss.total;
     if (events && done > 0) HIPCHK(hipMemcpy(events, h->d_log_event, (size_t)done * sizeof(cetkmc_event), hipMemcpyDeviceToHost));
     if (n_events && done > 0) HIPCHK(hipMemcpy(n_events, h->d_log_nev, (size_t)done * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- grain clustering (utils.get_clusters / dfs_cluster, utils.py:28-84) ---------------------------
+int cetkmc_cluster(void* handle, double threshold, int64_t* n_clusters)
+{
+    Handle* h = (Handle*)handle;
+    if (!h || !n_clusters) return fail("null argument");
+    if (h->slabs.size() != 1 || h->nranks != 1) return fail("cetkmc_cluster needs the whole lattice in one slab");
+    HIPCHK(hipSetDevice(h->dev));
+    const SlabView v = view_of(h, 0);
+    const int64_t n = (int64_t)h->L * h->L * h->L;
+    if (!h->d_cc_parent) {
+        HIPCHK(hipMalloc((void**)&h->d_cc_parent, n * sizeof(int)));
+        HIPCHK(hipMalloc((void**)&h->d_cc_roots, n * sizeof(int)));
+        HIPCHK(hipMalloc((void**)&h->d_cc_cid, n * sizeof(int)));
+        HIPCHK(hipMalloc((void**)&h->d_cc_labels, n * sizeof(int)));
+        HIPCHK(hipMalloc((void**)&h->d_cc_n, sizeof(int)));
+    }
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, 8192);
+    HIPCHK(hipMemsetAsync(h->d_cc_n, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_cc_init, dim3(grid), dim3(256), 0, h->stream, v, h->d_cc_parent);
+    hipLaunchKernelGGL(k_cc_hook, dim3(grid), dim3(256), 0, h->stream, v, h->d_cc_parent, threshold);
+    hipLaunchKernelGGL(k_cc_compress, dim3(grid), dim3(256), 0, h->stream, n, h->d_cc_parent, h->d_cc_roots, h->d_cc_n);
+    HIPCHK(hipGetLastError());
+    int nr = 0;
+    HIPCHK(hipMemcpyAsync(&nr, h->d_cc_n, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->cc_roots_sorted.resize((size_t)nr);
+    if (nr > 0) {
+        HIPCHK(hipMemcpy(h->cc_roots_sorted.data(), h->d_cc_roots, (size_t)nr * sizeof(int), hipMemcpyDeviceToHost));
+        std::sort(h->cc_roots_sorted.begin(), h->cc_roots_sorted.end());      // reference order: first voxel, row-major
+        HIPCHK(hipMemcpy(h->d_cc_roots, h->cc_roots_sorted.data(), (size_t)nr * sizeof(int), hipMemcpyHostToDevice));
+        if (h->d_cc_stats) { HIPCHK(hipFree(h->d_cc_stats)); h->d_cc_stats = nullptr; }
+        HIPCHK(hipMalloc((void**)&h->d_cc_stats, (size_t)nr * 8 * sizeof(int)));
+        const int g2 = (nr + 255) / 256;
+        hipLaunchKernelGGL(k_cc_ids, dim3(g2), dim3(256), 0, h->stream, (const int*)h->d_cc_roots, nr, h->d_cc_cid);
+        hipLaunchKernelGGL(k_cc_stats_init, dim3(g2), dim3(256), 0, h->stream, nr, h->d_cc_stats);
+    }
+    hipLaunchKernelGGL(k_cc_stats, dim3(grid), dim3(256), 0, h->stream, v, (const int*)h->d_cc_parent, (const int*)h->d_cc_cid,
+                       h->d_cc_labels, h->d_cc_stats);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->cc_n_clusters = nr;
+    *n_clusters = nr;
+    return 0;
+}
+
+int cetkmc_cluster_stats(void* handle, int64_t cap, int32_t* first_voxel, int64_t* size, int32_t* bbox)
+{
+    Handle* h = (Handle*)handle;
+    if (!h) return fail("null handle");
+    if (h->cc_n_clusters < 0) return fail("cetkmc_cluster_stats needs a preceding cetkmc_cluster");
+    const int64_t n = std::min<int64_t>(cap, h->cc_n_clusters);
+    if (n <= 0) return 0;
+    std::vector<int> st((size_t)n * 8);
+    HIPCHK(hipMemcpy(st.data(), h->d_cc_stats, st.size() * sizeof(int), hipMemcpyDeviceToHost));
+    const int L = h->L;
+    for (int64_t q = 0; q < n; ++q) {
+        const int r = h->cc_roots_sorted[(size_t)q];
+        if (first_voxel) { first_voxel[3 * q] = r / (L * L); first_voxel[3 * q + 1] = (r / L) % L; first_voxel[3 * q + 2] = r % L; }
+        if (size) size[q] = st[8 * q];
+        if (bbox) for (int c = 0; c < 6; ++c) bbox[6 * q + c] = st[8 * q + 1 + c];
+    }
+    return 0;
+}
+
+int cetkmc_cluster_labels(void* handle, int32_t* labels)
+{
+    Handle* h = (Handle*)handle;
+    if (!h || !labels) return fail("null argument");
+    if (h->cc_n_clusters < 0) return fail("cetkmc_cluster_labels needs a preceding cetkmc_cluster");
+    HIPCHK(hipMemcpy(labels, h->d_cc_labels, (size_t)h->L * h->L * h->L * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int cetkmc_species_counts(void* handle, int64_t counts[6])
+{
+    Handle* h = (Handle*)handle;
+    if (!h || !counts) return fail("null argument");
+    HIPCHK(hipSetDevice(h->dev));
+    unsigned long long* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, 6 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(d, 0, 6 * sizeof(unsigned long long), h->stream));
+    for (size_t s = 0; s < h->slabs.size(); ++s)
+        hipLaunchKernelGGL(k_species_counts, dim3(1024), dim3(256), 0, h->stream, view_of(h, (int)s), d);
+    HIPCHK(hipGetLastError());
+    unsigned long long out[6];
+    HIPCHK(hipMemcpyAsync(out, d, sizeof out, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipFree(d));
+    for (int c = 0; c < 6; ++c) counts[c] = (int64_t)out[c];
+    return 0;
+}
+
+int cetkmc_gather_species(void* handle, int species, int64_t* lin_idx, double* T_vals, int64_t cap, int64_t* n)
+{
+    Handle* h = (Handle*)handle;
+    if (!h || !n) return fail("null argument");
+    HIPCHK(hipSetDevice(h->dev));
+    unsigned long long* d_n = nullptr;
+    long long* d_idx = nullptr;
+    double* d_T = nullptr;
+    const size_t c = (size_t)std::max<int64_t>(cap, 1);
+    HIPCHK(hipMalloc((void**)&d_n, sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void**)&d_idx, c * sizeof(long long)));
+    HIPCHK(hipMalloc((void**)&d_T, c * sizeof(double)));
+    HIPCHK(hipMemsetAsync(d_n, 0, sizeof(unsigned long long), h->stream));
+    for (size_t s = 0; s < h->slabs.size(); ++s)
+        hipLaunchKernelGGL(k_gather_species, dim3(1024), dim3(256), 0, h->stream, view_of(h, (int)s), species, d_idx, d_T,
+                           (unsigned long long)(lin_idx && T_vals ? cap : 0), d_n);
+    HIPCHK(hipGetLastError());
+    unsigned long long cnt = 0;
+    HIPCHK(hipMemcpyAsync(&cnt, d_n, sizeof cnt, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *n = (int64_t)cnt;
+    const size_t m = (size_t)std::min<int64_t>((int64_t)cnt, cap);
+    if (lin_idx && T_vals && m > 0) {
+        HIPCHK(hipMemcpy(lin_idx, d_idx, m * sizeof(long long), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(T_vals, d_T, m * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    HIPCHK(hipFree(d_n)); HIPCHK(hipFree(d_idx)); HIPCHK(hipFree(d_T));
+    return 0;
+}
+
+int cetkmc_set_defects_sparse(void* handle, const int64_t* lin_idx, int64_t n)
+{
+    Handle* h = (Handle*)handle;
+    if (!h || (n > 0 && !lin_idx)) return fail("null argument");
+    HIPCHK(hipSetDevice(h->dev));
+    long long* d_idx = nullptr;
+    if (n > 0) {
+        HIPCHK(hipMalloc((void**)&d_idx, (size_t)n * sizeof(long long)));
+        HIPCHK(hipMemcpyAsync(d_idx, lin_idx, (size_t)n * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+    }
+    for (auto& s : h->slabs) {
+        HIPCHK(hipMemsetAsync(s.v.defects, 0, s.nS, h->stream));
+        if (n > 0) hipLaunchKernelGGL(k_scatter_defects, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0,
+                                      h->stream, s.v, (const long long*)d_idx, (long long)n);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (d_idx) HIPCHK(hipFree(d_idx));
+    h->swept = false;
     return 0;
 }
 

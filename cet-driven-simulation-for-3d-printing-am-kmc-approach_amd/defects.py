@@ -44,3 +44,22 @@ def introduce_defects(state, atom_type, T=None, apply_to_state=False, voxel_size
     if apply_to_state:
         state[mask == 1] = _DEFECT_STATE
     return mask, get_defect_density(mask, voxel_size)
+
+
+def refresh_defects_device(engine):
+    """introduce_defects(state, atom_type, T) for the lattice resident on the GPU without moving the
+    lattice: only the carbon sites (index + T) come to the host, the Bernoulli draws are taken from
+    NumPy's global stream in row-major site order exactly as track_defects does (defects.py:8-18), and
+    only the flagged indices go back.  Returns (number of flagged sites, density)."""
+    idx, t_here = engine.gather_species(_C_SITE)
+    L = engine.L
+    flagged = np.zeros(0, dtype=np.int64)
+    if len(idx):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t_here = np.where(t_here > 0, t_here, T_SUB)
+            p = DEFECT_PROB_BASE * np.exp(-0.3 / (K_T * t_here))
+        p = np.clip(p, 0.0, 1.0)
+        flagged = idx[np.random.random(len(idx)) < p]
+    engine.set_defects_sparse(flagged)
+    volume = (L ** 3) * (5e-6 ** 3)
+    return int(len(flagged)), (len(flagged) / volume if volume > 0 else 0.0)

@@ -23,10 +23,11 @@ import pandas as pd
 from constants import (ATOMIC_SPACING_W, CET_CHECK_INTERVAL, DEFECT_ID, LATTICE_SIZE,  # noqa: F401
                        METRIC_UPDATE_STEP, N_STEPS, NU_DEP, RANDOM_SEED, RATE_THRESHOLD, T_MELT, T_SUB,
                        VOXEL_SIZE)
-from defects import introduce_defects
+from defects import introduce_defects, refresh_defects_device
 from kmc_event_rates import get_event_rates  # noqa: F401  (re-exported like the reference)
 from lattice_init import initialize_lattice
-from metrics import compute_CET, compute_metrics, detect_CET_transition
+from metrics import compute_CET, compute_metrics, compute_metrics_device, detect_CET_transition  # noqa: F401
+from constants import CET_AR_THRESHOLD, CET_EQ_THRESHOLD
 from thermal_solver import update_temperature_cet as update_temperature  # noqa: F401
 
 THERMAL_EVERY = 20          # kmc_simulation.py:248
@@ -146,6 +147,7 @@ def run_kmc(
 
     engine = cetkmc.Engine(L, impurity_c=impurity_c)
     engine.upload(state, theta, phi, T, defects_mask)
+    n_flagged = int(np.sum(defects_mask))
 
     total_time = 0.0
     metrics_data = []
@@ -175,22 +177,22 @@ def run_kmc(
         step = stop
         next_step = stop + 1
 
-        fields = engine.download()
-        state, theta, phi, T = fields["state"], fields["theta"], fields["phi"], fields["T"]
-        atom_type = state.copy()
         is_metric_step = (step % METRIC_UPDATE_STEP == 0) or (step == n_steps - 1)
         if not is_metric_step:        # a pure checkpoint stop
-            save_checkpoint(os.path.join(output_dir, "checkpoint.npz"), fields, defects_mask, next_step, total_time,
+            fields = engine.download()
+            save_checkpoint(os.path.join(output_dir, "checkpoint.npz"), fields, engine.download(state=False, theta=False,
+                            phi=False, T=False, defects=True)["defects"], next_step, total_time,
                             nuc_offset + engine.nucleation_count(), metrics_data, cet_detected)
             continue
+        # Host work of a metrics step WITHOUT moving the lattice: the defect mask is refreshed from the
+        # carbon sites only, grains are clustered on the GPU, species are counted on the GPU.
         if step % METRIC_UPDATE_STEP == 0:
-            defects_mask, defect_density = introduce_defects(state, atom_type, T, apply_to_state=False)
-            engine.set_defects(defects_mask)
-
-        m = compute_metrics(state, theta, phi, defects=defects_mask, voxel_size=VOXEL_SIZE)
-        defect_voxels = int(np.sum(atom_type == DEFECT_ID))
+            n_flagged, defect_density = refresh_defects_device(engine)       # kmc_simulation.py:335-338
+        m = compute_metrics_device(engine, L ** 3, defects_count=n_flagged, voxel_size=VOXEL_SIZE)
+        counts = engine.species_counts()
+        defect_voxels = int(counts[DEFECT_ID])
         m["Defect_voxel_count"] = defect_voxels
-        m["DefectDensity"] = float(defect_voxels / atom_type.size)
+        m["DefectDensity"] = float(defect_voxels / (L ** 3))
         if (not cet_detected) and detect_CET_transition(m):
             cet_detected = True
             print(f"CET detected at step {step} (G/R={G / R:.2e})")
@@ -203,15 +205,16 @@ def run_kmc(
             "DefectDensity": m["DefectDensity"],
             "AvgGrainSize": m["AvgGrainSize"],
             "GrainCount": m["GrainCount"],
-            "W_Count": int((state == 1).sum()),
-            "Re_Count": int((state == 2).sum()),
-            "C_Count": int((state == 3).sum()),
+            "W_Count": int(counts[1]),
+            "Re_Count": int(counts[2]),
+            "C_Count": int(counts[3]),
             "NucleationCount": nuc_offset + engine.nucleation_count(),
             "G_over_R": (G / R) if R > 0 else np.inf,
             "G_phys": G,
             "R_phys": R_phys,
             "G_over_R_phys": G_over_R_phys,
-            "CET_Class": compute_CET(state, theta, phi, voxel_size=VOXEL_SIZE),
+            # compute_CET re-clusters the same lattice (metrics.py:99-101): same AR / equiaxed fraction
+            "CET_Class": "Equiaxed" if (m["AspectRatio"] < CET_AR_THRESHOLD and m["EquiaxedFraction"] > CET_EQ_THRESHOLD) else "Columnar",
             "CET_Detected": cet_detected,
         }
         metrics_data.append(row)
@@ -225,8 +228,9 @@ def run_kmc(
             f"Time={row['Time']:.2e}s"
         )
         if checkpoint_every > 0 and next_step % checkpoint_every == 0:
-            save_checkpoint(os.path.join(output_dir, "checkpoint.npz"), fields, defects_mask, next_step, total_time,
-                            nuc_offset + engine.nucleation_count(), metrics_data, cet_detected)
+            save_checkpoint(os.path.join(output_dir, "checkpoint.npz"), engine.download(),
+                            engine.download(state=False, theta=False, phi=False, T=False, defects=True)["defects"],
+                            next_step, total_time, nuc_offset + engine.nucleation_count(), metrics_data, cet_detected)
 
     if metrics_data:
         df = pd.DataFrame(metrics_data)

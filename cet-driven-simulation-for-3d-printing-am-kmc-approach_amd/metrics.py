@@ -105,6 +105,44 @@ def compute_metrics(state, theta, phi, defects=None, voxel_size=VOXEL_SIZE,
     }
 
 
+def compute_metrics_device(engine, n_voxels, defects_count=0, voxel_size=VOXEL_SIZE, rng_seed=None):
+    """Same dict as :func:`compute_metrics` (without the optional mask fractions), but the grain
+    clustering runs on the GPU on the lattice resident in ``engine`` (cetkmc_cluster: connected
+    components, numbered like the reference's DFS, utils.py:28-84).  Only the per-cluster sizes /
+    bounding boxes and the int32 label volume (for the d50/d90 quirk, metrics.py:76) cross PCIe."""
+    cl = engine.clusters(0.5, labels=True)
+    n = len(cl["size"])
+    if n == 0:
+        return {
+            "AspectRatio": 0.0, "EquiaxedFraction": 0.0, "NucleationDensity": 0.0,
+            "AvgGrainSize": 0.0, "GrainCount": 0, "DefectDensity": 0.0,
+            "Frac_W": 0.0, "Frac_Re": 0.0, "Frac_C": 0.0,
+            "C_boundary_frac": 0.0, "Re_boundary_frac": 0.0,
+            "Defect_voxel_count": 0, "Defect_voxel_frac": 0.0,
+            "Grain_d50_um": 0.0, "Grain_d90_um": 0.0,
+            "VOXEL_SIZE_m": voxel_size, "RANDOM_SEED": rng_seed,
+        }
+    dims = (cl["bbox"][:, 3:6] - cl["bbox"][:, 0:3] + 1).astype(np.int64)
+    ars = [float(lo_hi[1]) / float(max(lo_hi[0], 1)) for lo_hi in zip(dims.min(axis=1).tolist(), dims.max(axis=1).tolist())]
+    sizes = cl["size"].tolist()
+    volume = n_voxels * (voxel_size ** 3)
+    d50, d90 = equivalent_diameter_um(cl["labels"], voxel_size)
+    return {
+        "AspectRatio": np.mean(ars),
+        "EquiaxedFraction": np.mean(np.array(ars) < CET_AR_THRESHOLD),
+        "NucleationDensity": n / volume if volume > 0 else 0.0,
+        "AvgGrainSize": np.mean(sizes) * voxel_size * 1e6,
+        "GrainCount": n,
+        "DefectDensity": defects_count / volume if volume > 0 else 0.0,
+        "Frac_W": 0.0, "Frac_Re": 0.0, "Frac_C": 0.0,
+        "C_boundary_frac": 0.0, "Re_boundary_frac": 0.0,
+        "Defect_voxel_count": defects_count,
+        "Defect_voxel_frac": compute_voxel_fraction(defects_count, n_voxels),
+        "Grain_d50_um": d50, "Grain_d90_um": d90,
+        "VOXEL_SIZE_m": voxel_size, "RANDOM_SEED": rng_seed,
+    }
+
+
 def compute_CET(state, theta, phi, voxel_size=VOXEL_SIZE):
     m = compute_metrics(state, theta, phi, voxel_size=voxel_size)
     ok = m["AspectRatio"] < CET_AR_THRESHOLD and m["EquiaxedFraction"] > CET_EQ_THRESHOLD

@@ -178,6 +178,24 @@ int cetkmc_row_sums(void* handle, double* rowsum, int32_t* rowcnt);
 int cetkmc_run_steps(void* handle, const cetkmc_run_args* args, cetkmc_run_result* res,
                      double* totals, cetkmc_event* events, int64_t* n_events);
 
+/* Grain clustering on the device (utils.get_clusters / dfs_cluster, utils.py:28-84): connected
+ * components of occupied 14-stencil neighbours with misorientation < threshold, numbered 1.. in the
+ * order of their first voxel (row-major), exactly like the reference.  Whole lattice in one slab only.
+ * _stats: per cluster first voxel (i,j,k), voxel count, bounding box (imin,jmin,kmin,imax,jmax,kmax);
+ * _labels: the (L,L,L) int32 label volume the reference returns as `visited`. */
+int cetkmc_cluster(void* handle, double threshold, int64_t* n_clusters);
+int cetkmc_cluster_stats(void* handle, int64_t cap, int32_t* first_voxel, int64_t* size, int32_t* bbox);
+int cetkmc_cluster_labels(void* handle, int32_t* labels);
+
+/* Sparse site queries so that the host-side defect model (defects.track_defects, defects.py:4-19) and the
+ * species counts of the metrics row (kmc_simulation.py:355-357) need no full-lattice transfer:
+ * counts[s] = owned voxels in state s (0..4; [5] = other); gather: global linear index ((i*L+j)*L+k) and T of
+ * every owned voxel of the given species (unordered, *n = total found; at most cap are written);
+ * set_defects_sparse: defects := 0, then 1 at the listed voxels. */
+int cetkmc_species_counts(void* handle, int64_t counts[6]);
+int cetkmc_gather_species(void* handle, int species, int64_t* lin_idx, double* T_vals, int64_t cap, int64_t* n);
+int cetkmc_set_defects_sparse(void* handle, const int64_t* lin_idx, int64_t n);
+
 int64_t cetkmc_nucleation_count(void* handle);
 int cetkmc_reset_counters(void* handle);
 
