@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--L", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-incremental", action="store_true", help="skip the extra exact-incremental-mode run")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-process code path (gloo rendezvous + RCCL communicator) even with one rank")
@@ -130,11 +131,11 @@ def main():
         return dict(step0=step0, n=n, u_pick=u_pick[step0:], u_def=u_def[step0:], u_np=u_np,
                     q=synthetic.laser_planes(L, step0, n))
 
-    def run(step0, n, profile=False, logs=False, prep=None):
+    def run(step0, n, profile=False, logs=False, prep=None, incremental=False):
         b = prep or prepare(step0, n)
         return eng.run_steps(step0, n, DEFECT_FRACTION, b["u_pick"], b["u_def"], b["u_np"][run.np_pos:],
                              rng_mode=1, seed=SEED, thermal_mode=2, q_planes=b["q"], use_latent=True,
-                             profile=profile, want_logs=True)
+                             profile=profile, want_logs=True, incremental=incremental)
     run.np_pos = 0
 
     def barrier():
@@ -176,6 +177,28 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
+
+    # ---- after the timed region: the same loop in exact incremental mode (reported beside `value`, never as it)
+    inc = None
+    if not a.no_incremental:
+        run.np_pos += r["np_used"]
+        inc_inputs = prepare(step + a.steps, a.steps)
+        barrier()
+        t1 = time.perf_counter()
+        ri = run(step + a.steps, a.steps, prep=inc_inputs, incremental=True)
+        barrier()
+        dti = time.perf_counter() - t1
+        if dist is not None:
+            import torch
+            t = torch.tensor([dti], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dti = float(t[0])
+        if ri["done"] == a.steps:
+            inc = {"steps_per_s": a.steps / dti, "ms_per_step": 1e3 * dti / a.steps, "full_sweeps": ri["full_sweeps"],
+                   "steps": a.steps,
+                   "note": "cetkmc_run_steps incremental=1 on the following K steps: between temperature updates only the "
+                           "rows the previous event made stale are re-evaluated; bit-identical to full sweeps "
+                           "(tests/test_gpu_parity.py::test_incremental_mode_bit_identical); not part of `value`"}
 
     cand = float(np.sum(r["n_events"].astype(np.float64)))     # identical on every rank (global counts)
     steps_per_s = a.steps / dt
@@ -220,6 +243,8 @@ def main():
             "steps_per_s": base["steps"] / base["seconds"], "host_cores_available": os.cpu_count(),
             "parity_first_steps": base["parity"],
         }
+    if inc is not None:
+        out["incremental_exact"] = inc
     if rank == 0:
         print(json.dumps(out))
     eng.close()

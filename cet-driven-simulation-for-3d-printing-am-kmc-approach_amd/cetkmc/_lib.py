@@ -40,7 +40,7 @@ class RunArgs(C.Structure):
         ("u_pick", C.POINTER(C.c_double)), ("u_defect", C.POINTER(C.c_double)), ("u_np", C.POINTER(C.c_double)),
         ("np_cap", C.c_int64), ("rng_mode", C.c_int32), ("seed", C.c_uint64), ("thermal_mode", C.c_int32),
         ("thermal_dt", C.c_double), ("q_planes", C.POINTER(C.c_double)), ("n_q", C.c_int64),
-        ("use_latent", C.c_int32), ("profile", C.c_int32),
+        ("use_latent", C.c_int32), ("profile", C.c_int32), ("incremental", C.c_int32),
     ]
 
 
@@ -48,7 +48,7 @@ class RunResult(C.Structure):
     _fields_ = [
         ("steps_done", C.c_int64), ("status", C.c_int32), ("np_used", C.c_int64), ("q_used", C.c_int64),
         ("nucleation_count", C.c_int64), ("sweep_ms_total", C.c_double), ("sweep_launches", C.c_int64),
-        ("wall_ms", C.c_double),
+        ("wall_ms", C.c_double), ("full_sweeps", C.c_int64),
     ]
 
 

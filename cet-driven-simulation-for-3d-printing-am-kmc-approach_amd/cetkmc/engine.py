@@ -227,7 +227,7 @@ class Engine:
 
     # -- batched loop ------------------------------------------------------------------------
     def run_steps(self, step0, n, defect_fraction, u_pick, u_defect, u_np, rng_mode=0, seed=0, thermal_mode=1,
-                  thermal_dt=1e-6, q_planes=None, use_latent=True, profile=False, want_logs=True):
+                  thermal_dt=1e-6, q_planes=None, use_latent=True, profile=False, want_logs=True, incremental=False):
         a = RunArgs()
         u_pick = np.ascontiguousarray(u_pick, dtype=np.float64)
         u_defect = None if u_defect is None else np.ascontiguousarray(u_defect, dtype=np.float64)
@@ -239,6 +239,7 @@ class Engine:
         a.thermal_mode, a.thermal_dt = int(thermal_mode), float(thermal_dt)
         a.q_planes, a.n_q = _dptr(q), (0 if q is None else q.shape[0])
         a.use_latent, a.profile = int(bool(use_latent)), int(bool(profile))
+        a.incremental = int(bool(incremental))
         res = RunResult()
         totals = np.zeros(n + 1, np.float64) if want_logs else None
         events = np.zeros(max(n, 1), dtype=EVENT_DTYPE) if want_logs else None
@@ -247,7 +248,7 @@ class Engine:
         done = res.steps_done
         out = dict(done=int(done), status=int(res.status), np_used=int(res.np_used), q_used=int(res.q_used),
                    nucleation_count=int(res.nucleation_count), sweep_ms_total=res.sweep_ms_total,
-                   sweep_launches=int(res.sweep_launches), wall_ms=res.wall_ms)
+                   sweep_launches=int(res.sweep_launches), wall_ms=res.wall_ms, full_sweeps=int(res.full_sweeps))
         if want_logs:
             out.update(totals=totals[:done + (1 if res.status == 1 else 0)], events=events[:done], n_events=nev[:done])
         return out

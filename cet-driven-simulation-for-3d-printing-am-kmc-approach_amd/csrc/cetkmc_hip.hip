@@ -105,6 +105,7 @@ struct Handle {
     BlockEnt* d_blocks = nullptr;
     cetkmc_event* d_events_all = nullptr;
     StepState* d_ss = nullptr;
+    int* d_dirty = nullptr;      // [1 + DIRTY_MAX] rows made stale by the last applied event (incremental mode)
     double* d_ktab = nullptr;
     KParams* d_kp = nullptr;
     void* d_scratch = nullptr;
@@ -276,6 +277,8 @@ int create_common(const cetkmc_params* p, int L, const std::vector<std::pair<int
     HIPCHK(hipMemsetAsync(h->d_events_all, 0xFF, (size_t)G * sizeof(cetkmc_event), h->stream));   // type = -1
     HIPCHK(hipMalloc((void**)&h->d_ss, sizeof(StepState)));
     HIPCHK(hipMemsetAsync(h->d_ss, 0, sizeof(StepState), h->stream));
+    HIPCHK(hipMalloc((void**)&h->d_dirty, (1 + DIRTY_MAX) * sizeof(int)));
+    HIPCHK(hipMemsetAsync(h->d_dirty, 0, (1 + DIRTY_MAX) * sizeof(int), h->stream));
     HIPCHK(hipMalloc((void**)&h->d_ktab, 225 * sizeof(double)));
     HIPCHK(hipMalloc((void**)&h->d_kp, sizeof(KParams)));
     HIPCHK(hipMalloc((void**)&h->d_flag, sizeof(int)));
@@ -424,6 +427,39 @@ int launch_interface(Handle* h, bool batch, hipStream_t st)
     return 0;
 }
 
+StreamArgs stream_args(Handle* h, const SlabView& v)
+{
+    StreamArgs sa{};
+    sa.T_melt = h->kp.T_melt; sa.delta_T_c = h->kp.delta_T_c; sa.kT = h->kp.kT; sa.I0 = h->kp.I0;
+    sa.rate_threshold = h->kp.rate_threshold; sa.nu_dep = h->kp.nu_dep;
+    sa.L = v.L; sa.gi0 = v.gi0; sa.nloc = v.nloc; sa.RJ = v.RJ; sa.pitchC = v.pitchC; sa.pitchT = v.pitchT; sa.Pk = v.Pk;
+    sa.cls = v.cls; sa.T = v.T; sa.ifc_val = v.ifc_val; sa.ifc_cnt = v.ifc_cnt; sa.rowsum = v.rowsum; sa.rowcnt = v.rowcnt;
+    sa.group_first = 0; sa.group_count = (v.nloc + STREAM_NI - 1) / STREAM_NI;
+    return sa;
+}
+
+// Incremental step (run_steps with incremental = 1, between temperature updates): only the rows the
+// previous event made stale are re-evaluated; their planes' block sums follow.
+int launch_dirty_rows(Handle* h, hipEvent_t ev_a, hipEvent_t ev_b)
+{
+    if (ev_a) HIPCHK(hipEventRecord(ev_a, h->stream));
+    for (size_t s = 0; s < h->slabs.size(); ++s) {
+        SlabView v = view_of(h, (int)s);
+        hipLaunchKernelGGL(k_rows_eval, dim3(24), dim3(64), 0, h->stream, stream_args(h, v), h->d_ktab, (const int*)h->d_dirty, (const StepState*)h->d_ss);
+    }
+    if (ev_b) HIPCHK(hipEventRecord(ev_b, h->stream));
+    for (size_t s = 0; s < h->slabs.size(); ++s)
+        hipLaunchKernelGGL(k_plane_reduce_dirty, dim3(24 * 3), dim3(64), 0, h->stream, view_of(h, (int)s), h->d_blocks,
+                           (const int*)h->d_dirty, (const StepState*)h->d_ss);
+    HIPCHK(hipGetLastError());
+    if (h->comm) {
+        const size_t per = (size_t)3 * (h->L / h->nranks) * sizeof(BlockEnt);
+        NCCLCHK(g_rccl.AllGather((const char*)h->d_blocks + per * h->rank, h->d_blocks, per, ncclChar, h->comm, h->stream));
+    }
+    h->swept = true;
+    return 0;
+}
+
 int launch_sweep(Handle* h, bool batch, hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr, bool skip_ifc = false)
 {
     const int TR = SWEEP_TJ + 4;
@@ -435,13 +471,8 @@ int launch_sweep(Handle* h, bool batch, hipEvent_t ev_a = nullptr, hipEvent_t ev
     for (size_t s = 0; s < h->slabs.size(); ++s) {
         SlabView v = view_of(h, (int)s);
         if (h->sweep_variant == 1) {
-            StreamArgs sa{};
-            sa.T_melt = h->kp.T_melt; sa.delta_T_c = h->kp.delta_T_c; sa.kT = h->kp.kT; sa.I0 = h->kp.I0;
-            sa.rate_threshold = h->kp.rate_threshold; sa.nu_dep = h->kp.nu_dep;
-            sa.L = v.L; sa.gi0 = v.gi0; sa.nloc = v.nloc; sa.RJ = v.RJ; sa.pitchC = v.pitchC; sa.pitchT = v.pitchT; sa.Pk = v.Pk;
-            sa.cls = v.cls; sa.T = v.T; sa.ifc_val = v.ifc_val; sa.ifc_cnt = v.ifc_cnt; sa.rowsum = v.rowsum; sa.rowcnt = v.rowcnt;
-            const int nib = (v.nloc + STREAM_NI - 1) / STREAM_NI;
-            sa.group_first = 0; sa.group_count = nib;
+            const StreamArgs sa = stream_args(h, v);
+            const int nib = sa.group_count;
             if (h->stream_tj == 8) {
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_stream<8>), dim3(nib * ((h->L + 7) / 8)), dim3(256), h->shmem_stream, h->stream, sa, h->d_ktab, ss);
             } else {
@@ -563,7 +594,7 @@ void destroy_impl(Handle* h)
     }
     void* ccp[] = {h->d_cc_parent, h->d_cc_roots, h->d_cc_cid, h->d_cc_labels, h->d_cc_stats, h->d_cc_n};
     for (void* p : ccp) if (p) (void)hipFree(p);
-    void* ptrs[] = {h->d_views[0], h->d_views[1], h->d_blocks, h->d_events_all, h->d_ss, h->d_ktab, h->d_kp, h->d_scratch,
+    void* ptrs[] = {h->d_views[0], h->d_views[1], h->d_blocks, h->d_events_all, h->d_ss, h->d_dirty, h->d_ktab, h->d_kp, h->d_scratch,
                     h->d_flag, h->d_qtop, h->d_u_pick, h->d_u_defect, h->d_u_np, h->d_q, h->d_log_total,
                     h->d_log_event, h->d_log_nev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -941,8 +972,23 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     int64_t q_idx = 0;
     bool ifc_fresh = false;     // ifc_val already holds this step's interface sums (speculative launch of the previous step)
+    const bool incr = a->incremental && h->sweep_variant == 1;
+    res->full_sweeps = 0;
     for (int64_t s = 0; s < n; ++s) {
         const int64_t g = a->step0 + s;
+        const bool therm = a->thermal_mode && g % 20 == 0;
+        if (incr && s > 0 && !therm) {
+            // exact incremental step: rates can only have changed in the rows recorded by the last apply
+            CHK(launch_dirty_rows(h, a->profile ? h->prof[2 * s] : nullptr, a->profile ? h->prof[2 * s + 1] : nullptr));
+            CHK(launch_select(h, cfg, 0.0, 0));
+            hipLaunchKernelGGL(k_apply_batch, dim3(1), dim3(64), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
+                               (int)h->slabs.size(), h->L, (const cetkmc_event*)h->d_events_all, h->G, h->d_ss, cfg,
+                               (const double*)h->d_u_defect, (const double*)h->d_u_np, h->d_log_total, h->d_log_event,
+                               h->d_log_nev, (const double*)h->d_ktab, 1, h->d_dirty);
+            h->swept = false;
+            continue;
+        }
+        ++res->full_sweeps;
         if (a->thermal_mode && g % 20 == 0) {
             if (a->thermal_mode == 1) CHK(launch_thermal(h, a->thermal_dt, 0, nullptr, 0, 1, true));
             else { CHK(launch_thermal(h, a->thermal_dt, 1, h->d_q + (size_t)q_idx * L2, a->use_latent, 1, true)); ++q_idx; }
@@ -965,7 +1011,7 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
         hipLaunchKernelGGL(k_apply_batch, dim3(1), dim3(64), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
                            (int)h->slabs.size(), h->L, (const cetkmc_event*)h->d_events_all, h->G, h->d_ss, cfg,
                            (const double*)h->d_u_defect, (const double*)h->d_u_np, h->d_log_total, h->d_log_event,
-                           h->d_log_nev, (const double*)h->d_ktab, spec ? 1 : 0);
+                           h->d_log_nev, (const double*)h->d_ktab, (spec || incr) ? 1 : 0, incr ? h->d_dirty : nullptr);
         ifc_fresh = spec;
         h->swept = false;
     }

@@ -216,6 +216,112 @@ struct StreamArgs {
 
 __device__ __forceinline__ unsigned alignbit16(unsigned hi, unsigned lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
 
+// One lattice row (plane li, row j) by one wave: census + rates + canonical row reduction, results to
+// rowsum/rowcnt.  `rowp(d, dj)` returns the class-row pointer (at k = 0) of plane li+d, row j+dj -- an LDS
+// ring slot in the streaming kernel, the global class array in the dirty-row kernel; everything else is
+// shared, so both produce bit-identical row sums.  `rp` = LDS scratch [3][STREAM_MAXCH] of this row.
+template <class ROWP>
+__device__ __forceinline__ void sweep_row(const StreamArgs& A, const double* ktab, double* rp, ROWP rowp,
+                                          int li, int lp, int j, bool top, int lane, int nch)
+{
+    const int L = A.L;
+    int cdep = 0, cdiff = 0, cemp = 0;
+#pragma unroll 1
+    for (int m = 0; m < nch; ++m) {
+        const int k0 = (m << 8) + 4 * lane;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;     // 4-voxel trees (v0+v1)+(v2+v3), built pair by pair
+        if (j < L && k0 < L) {
+            const int64_t trow = ((int64_t)li * L + j) * A.pitchT + k0;
+            const double2 Ta = *reinterpret_cast<const double2*>(A.T + trow);
+            const double2 Tb = (k0 + 2 < L) ? *reinterpret_cast<const double2*>(A.T + trow + 2) : make_double2(0.0, 0.0);
+            // ---- SWAR census of the 4 voxels' 14 neighbours ------------------------------
+            auto ld2 = [&](const uint16_t* p) { return *reinterpret_cast<const uint2*>(p + k0); };
+            auto ld1 = [&](const uint16_t* p) { return *reinterpret_cast<const unsigned*>(p + k0); };
+            uint2 acc = ld2(rowp(1, 1));
+            uint2 t;
+            t = ld2(rowp(1, -1)); acc.x += t.x; acc.y += t.y;
+            t = ld2(rowp(-1, 1)); acc.x += t.x; acc.y += t.y;
+            t = ld2(rowp(-1, -1)); acc.x += t.x; acc.y += t.y;
+            t = ld2(rowp(2, 0)); acc.x += t.x; acc.y += t.y;
+            t = ld2(rowp(-2, 0)); acc.x += t.x; acc.y += t.y;
+            t = ld2(rowp(0, 2)); acc.x += t.x; acc.y += t.y;
+            t = ld2(rowp(0, -2)); acc.x += t.x; acc.y += t.y;
+#pragma unroll
+            for (int dj = -1; dj <= 1; dj += 2) {          // (0,dj,+-1): neighbours k-1 and k+1
+                const uint16_t* p = rowp(0, dj);
+                const unsigned Aw = ld1(p - 2), Cw = ld1(p + 4);
+                const uint2 B = ld2(p);
+                const unsigned m1 = alignbit16(B.x, Aw), m2 = alignbit16(B.y, B.x), m3 = alignbit16(Cw, B.y);
+                acc.x += m1 + m2; acc.y += m2 + m3;
+            }
+            const uint16_t* po = rowp(0, 0);                 // own row: neighbours k-2 and k+2
+            const unsigned Aw = ld1(po - 2), Cw = ld1(po + 4);
+            const uint2 own = ld2(po);
+            acc.x += Aw + own.y; acc.y += own.x + Cw;
+            // ---- per-voxel part (two voxels per trip: keeps the register footprint small) ----
+            double p0 = 0.0, p1 = 0.0, p2 = 0.0;             // even voxel of the current pair
+#pragma unroll 2
+            for (int h = 0; h < 4; ++h) {
+                const int sh = 16 * (h & 1);
+                const unsigned f = ((h < 2 ? acc.x : acc.y) >> sh) & 0xFFFFu;
+                const unsigned oc = ((h < 2 ? own.x : own.y) >> sh) & 0xFFFFu;
+                const bool empty = (oc & 0x10u) != 0;
+                double ev = 0.0, dv = 0.0, depv = 0.0;
+                if (empty) {
+                    const double Traw = (h < 2) ? (h == 0 ? Ta.x : Ta.y) : (h == 2 ? Tb.x : Tb.y);
+                    const double Tc = pymax(Traw, 1.0);
+                    if (top) {
+                        const double rate = A.nu_dep * exp(-(A.T_melt - Tc) / (A.kT * Tc));
+                        if (finite_d(rate)) { depv = rate; ++cdep; }
+                    }
+                    if (f & 0x0F00u) {                       // has W/Re/C neighbours: interface voxel
+                        ev = A.ifc_val[trow + h];
+                        cemp += A.ifc_cnt[trow + h];
+                    } else {
+                        const double dT = A.T_melt - Tc;
+                        if (dT > A.delta_T_c) {
+                            const int n_nb = f & 15, n_imp = (f >> 12) & 15;
+                            const double rate = nuc_rate_s(A.I0, ktab[n_nb * 15 + n_imp], dT, A.kT * Tc);
+                            if (rate > A.rate_threshold) { ev = rate; ++cemp; }   // <= I0: always finite
+                        }
+                    }
+                } else if ((oc & 0x100u) && (f & 0x00F0u)) { // atom with empty neighbours
+                    dv = A.ifc_val[trow + h];
+                    cdiff += A.ifc_cnt[trow + h];
+                }
+                if (!(h & 1)) { p0 = depv; p1 = dv; p2 = ev; }
+                else if (h == 1) { s0 = p0 + depv; s1 = p1 + dv; s2 = p2 + ev; }
+                else { s0 = s0 + (p0 + depv); s1 = s1 + (p1 + dv); s2 = s2 + (p2 + ev); }
+            }
+        }
+        // ---- wave butterfly, chunk partial to LDS ---------------------------------------------
+        if (__any(s2 != 0.0)) s2 = wave_tree_sum(s2);
+        if (__any(s1 != 0.0)) s1 = wave_tree_sum(s1);
+        if (top && __any(s0 != 0.0)) s0 = wave_tree_sum(s0);
+        if (lane == 0) {
+            rp[0 * STREAM_MAXCH + m] = s0;
+            rp[1 * STREAM_MAXCH + m] = s1;
+            rp[2 * STREAM_MAXCH + m] = s2;
+        }
+    }
+    // ---- row totals: balanced tree over the chunk partials; counts reduced once ------------
+    // per-lane counts are <= 4*nch*15 < 2^10 each, so diff and empty share one integer butterfly
+    const int packed = wave_sum_i(cemp | (cdiff << 16));
+    const int n2 = packed & 0xFFFF, n1 = packed >> 16;
+    const int n0 = top ? wave_sum_i(cdep) : 0;
+    if (lane == 0 && j < L) {
+        const int64_t o = (int64_t)lp * 3 * L + j;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double* p = rp + c * STREAM_MAXCH;
+            for (int n = nch; n > 1; n >>= 1)
+                for (int t = 0; t < (n >> 1); ++t) p[t] = p[2 * t] + p[2 * t + 1];
+            A.rowsum[o + (int64_t)c * L] = p[0];
+        }
+        A.rowcnt[o] = n0; A.rowcnt[o + L] = n1; A.rowcnt[o + 2 * L] = n2;
+    }
+}
+
 template <int TJ>
 __global__ __launch_bounds__(256) void k_sweep_stream(StreamArgs A, const double* __restrict__ ktab_g,
                                                       const StepState* __restrict__ ss)
@@ -260,106 +366,63 @@ __global__ __launch_bounds__(256) void k_sweep_stream(StreamArgs A, const double
         for (int d = 0; d < 5; ++d) so[d] = ((li - 2 + d) % 5) * slab;
 #pragma unroll 1
         for (int rr = 0; rr < TJ / 4; ++rr) {
-            const int r = w + 4 * rr, j = j0 + r;
-            int cdep = 0, cdiff = 0, cemp = 0;
-#pragma unroll 1
-            for (int m = 0; m < nch; ++m) {
-                const int k0 = (m << 8) + 4 * lane;
-                double s0 = 0.0, s1 = 0.0, s2 = 0.0;     // 4-voxel trees (v0+v1)+(v2+v3), built pair by pair
-                if (j < L && k0 < L) {
-                    const int64_t trow = ((int64_t)li * L + j) * A.pitchT + k0;
-                    const double2 Ta = *reinterpret_cast<const double2*>(A.T + trow);
-                    const double2 Tb = (k0 + 2 < L) ? *reinterpret_cast<const double2*>(A.T + trow + 2) : make_double2(0.0, 0.0);
-                    // ---- SWAR census of the 4 voxels' 14 neighbours ------------------------------
-                    auto rowp = [&](int d, int row) { return ring + so[d + 2] + row * pitchC + KOFFC + k0; };
-                    auto ld2 = [&](const uint16_t* p) { return *reinterpret_cast<const uint2*>(p); };
-                    auto ld1 = [&](const uint16_t* p) { return *reinterpret_cast<const unsigned*>(p); };
-                    uint2 acc = ld2(rowp(1, r + 3));
-                    uint2 t;
-                    t = ld2(rowp(1, r + 1)); acc.x += t.x; acc.y += t.y;
-                    t = ld2(rowp(-1, r + 3)); acc.x += t.x; acc.y += t.y;
-                    t = ld2(rowp(-1, r + 1)); acc.x += t.x; acc.y += t.y;
-                    t = ld2(rowp(2, r + 2)); acc.x += t.x; acc.y += t.y;
-                    t = ld2(rowp(-2, r + 2)); acc.x += t.x; acc.y += t.y;
-                    t = ld2(rowp(0, r + 4)); acc.x += t.x; acc.y += t.y;
-                    t = ld2(rowp(0, r + 0)); acc.x += t.x; acc.y += t.y;
-#pragma unroll
-                    for (int dj = -1; dj <= 1; dj += 2) {          // (0,dj,+-1): neighbours k-1 and k+1
-                        const uint16_t* p = rowp(0, r + 2 + dj);
-                        const unsigned Aw = ld1(p - 2), Cw = ld1(p + 4);
-                        const uint2 B = ld2(p);
-                        const unsigned m1 = alignbit16(B.x, Aw), m2 = alignbit16(B.y, B.x), m3 = alignbit16(Cw, B.y);
-                        acc.x += m1 + m2; acc.y += m2 + m3;
-                    }
-                    const uint16_t* po = rowp(0, r + 2);             // own row: neighbours k-2 and k+2
-                    const unsigned Aw = ld1(po - 2), Cw = ld1(po + 4);
-                    const uint2 own = ld2(po);
-                    acc.x += Aw + own.y; acc.y += own.x + Cw;
-                    // ---- per-voxel part (one voxel at a time: keeps the register footprint small) ----
-                    double p0 = 0.0, p1 = 0.0, p2 = 0.0;             // even voxel of the current pair
-#pragma unroll 2
-                    for (int h = 0; h < 4; ++h) {
-                        const int sh = 16 * (h & 1);
-                        const unsigned f = ((h < 2 ? acc.x : acc.y) >> sh) & 0xFFFFu;
-                        const unsigned oc = ((h < 2 ? own.x : own.y) >> sh) & 0xFFFFu;
-                        const bool empty = (oc & 0x10u) != 0;
-                        double ev = 0.0, dv = 0.0, depv = 0.0;
-                        if (empty) {
-                            const double Traw = (h < 2) ? (h == 0 ? Ta.x : Ta.y) : (h == 2 ? Tb.x : Tb.y);
-                            const double Tc = pymax(Traw, 1.0);
-                            if (top) {
-                                const double rate = A.nu_dep * exp(-(A.T_melt - Tc) / (A.kT * Tc));
-                                if (finite_d(rate)) { depv = rate; ++cdep; }
-                            }
-                            if (f & 0x0F00u) {                       // has W/Re/C neighbours: interface voxel
-                                ev = A.ifc_val[trow + h];
-                                cemp += A.ifc_cnt[trow + h];
-                            } else {
-                                const double dT = A.T_melt - Tc;
-                                if (dT > A.delta_T_c) {
-                                    const int n_nb = f & 15, n_imp = (f >> 12) & 15;
-                                    const double rate = nuc_rate_s(A.I0, ktab[n_nb * 15 + n_imp], dT, A.kT * Tc);
-                                    if (rate > A.rate_threshold) { ev = rate; ++cemp; }   // <= I0: always finite
-                                }
-                            }
-                        } else if ((oc & 0x100u) && (f & 0x00F0u)) { // atom with empty neighbours
-                            dv = A.ifc_val[trow + h];
-                            cdiff += A.ifc_cnt[trow + h];
-                        }
-                        if (!(h & 1)) { p0 = depv; p1 = dv; p2 = ev; }
-                        else if (h == 1) { s0 = p0 + depv; s1 = p1 + dv; s2 = p2 + ev; }
-                        else { s0 = s0 + (p0 + depv); s1 = s1 + (p1 + dv); s2 = s2 + (p2 + ev); }
-                    }
-                }
-                // ---- wave butterfly, chunk partial to LDS ---------------------------------------------
-                if (__any(s2 != 0.0)) s2 = wave_tree_sum(s2);
-                if (__any(s1 != 0.0)) s1 = wave_tree_sum(s1);
-                if (top && __any(s0 != 0.0)) s0 = wave_tree_sum(s0);
-                if (lane == 0) {
-                    rowpart[(r * 3 + 0) * STREAM_MAXCH + m] = s0;
-                    rowpart[(r * 3 + 1) * STREAM_MAXCH + m] = s1;
-                    rowpart[(r * 3 + 2) * STREAM_MAXCH + m] = s2;
-                }
-            }
-            // ---- row totals: balanced tree over the chunk partials; counts reduced once ------------
-            // per-lane counts are <= 4*nch*15 < 2^10 each, so diff and empty share one integer butterfly
-            const int packed = wave_sum_i(cemp | (cdiff << 16));
-            const int n2 = packed & 0xFFFF, n1 = packed >> 16;
-            const int n0 = top ? wave_sum_i(cdep) : 0;
-            if (lane == 0 && j < L) {
-                const int64_t o = (int64_t)lp * 3 * L + j;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    double* p = rowpart + (r * 3 + c) * STREAM_MAXCH;
-                    for (int n = nch; n > 1; n >>= 1)
-                        for (int t = 0; t < (n >> 1); ++t) p[t] = p[2 * t] + p[2 * t + 1];
-                    A.rowsum[o + (int64_t)c * L] = p[0];
-                }
-                A.rowcnt[o] = n0; A.rowcnt[o + L] = n1; A.rowcnt[o + 2 * L] = n2;
-            }
+            const int r = w + 4 * rr;
+            auto rowp = [&](int d, int dj) { return ring + so[d + 2] + (r + 2 + dj) * pitchC + KOFFC; };
+            sweep_row(A, ktab, rowpart + r * 3 * STREAM_MAXCH, rowp, li, lp, j0 + r, top, lane, nch);
         }
         __syncthreads();   // ring slot (li-2)%5 is overwritten by the next plane's load
     }
+}
+
+// Exact incremental stepping: between two temperature updates an event changes the rates of a few rows
+// only (those holding the changed voxel(s) or one of their 14 neighbours).  k_apply_batch records those
+// rows; this kernel re-evaluates just them -- one wave per row, class words read straight from global
+// memory -- with the same sweep_row() as the streaming kernel, so every row sum equals what a full sweep
+// would have produced.  dirty[0] = count, dirty[1..] = (global plane << 16) | row.
+constexpr int DIRTY_MAX = 63;
+__global__ __launch_bounds__(64) void k_rows_eval(StreamArgs A, const double* __restrict__ ktab_g, const int* __restrict__ dirty,
+                                                  const StepState* __restrict__ ss)
+{
+    if (ss && ss->status) return;
+    __shared__ double ktab[226];
+    __shared__ double rp[3 * STREAM_MAXCH];
+    if ((int)blockIdx.x >= dirty[0]) return;
+    const int e = dirty[1 + blockIdx.x];
+    const int i = e >> 16, j = e & 0xFFFF;
+    const int lp = i - A.gi0;
+    if (lp < 0 || lp >= A.nloc) return;                     // another slab's row
+    const int lane = threadIdx.x;
+    for (int t = lane; t < 225; t += 64) ktab[t] = ktab_g[t];
+    __syncthreads();
+    const int li = lp + 2;
+    const int nch = A.Pk > 256 ? (A.Pk >> 8) : 1;
+    auto rowp = [&](int d, int dj) { return A.cls + ((int64_t)(li + d) * A.RJ + (j + 2 + dj)) * A.pitchC + KOFFC; };
+    sweep_row(A, ktab, rp, rowp, li, lp, j, A.gi0 + lp == A.L - 1, lane, nch);
+}
+// block sums of the planes that own a dirty row (duplicates recompute the same value)
+__global__ __launch_bounds__(64) void k_plane_reduce_dirty(SlabView S, BlockEnt* __restrict__ blocks, const int* __restrict__ dirty,
+                                                           const StepState* __restrict__ ss)
+{
+    if (ss && ss->status) return;
+    const int e_idx = blockIdx.x / 3, c = blockIdx.x - 3 * e_idx;
+    if (e_idx >= dirty[0]) return;
+    const int lp = (dirty[1 + e_idx] >> 16) - S.gi0;
+    if (lp < 0 || lp >= S.nloc) return;
+    const int b = lp * 3 + c, lane = threadIdx.x;
+    const int nch = S.Pk > 64 ? (S.Pk >> 6) : 1;
+    double stk[5];
+    double tot = 0.0;
+    int64_t cnt = 0;
+    for (int m = 0; m < nch; ++m) {
+        const int j = (m << 6) + lane;
+        double v = 0.0;
+        int cv = 0;
+        if (j < S.L) { v = S.rowsum[(int64_t)b * S.L + j]; cv = S.rowcnt[(int64_t)b * S.L + j]; }
+        v = wave_tree_sum(v);
+        cnt += wave_sum_i(cv);
+        tot = stack_push(stk, v, m);
+    }
+    if (lane == 0) { blocks[3 * (S.gi0 + lp) + c].sum = tot; blocks[3 * (S.gi0 + lp) + c].cnt = cnt; }
 }
 
 // k_plane_reduce: one wave per (owned plane, category): balanced tree over j of the row sums.
@@ -790,7 +853,7 @@ __global__ __launch_bounds__(64) void k_apply_batch(KParams P, const SlabView* _
                                                     BatchCfg cfg, const double* __restrict__ u_defect,
                                                     const double* __restrict__ u_np, double* log_total,
                                                     cetkmc_event* log_event, int64_t* log_nev,
-                                                    const double* __restrict__ ktab_g, int eval_touched)
+                                                    const double* __restrict__ ktab_g, int eval_touched, int* dirty)
 {
     __shared__ cetkmc_event sh_ev;
     __shared__ int sh_ok;
@@ -832,6 +895,25 @@ __global__ __launch_bounds__(64) void k_apply_batch(KParams P, const SlabView* _
     }
     __syncthreads();
     if (sh_ok) apply_touch(P, slabs, nslabs, ktab_g, sh_ev, threadIdx.x, eval_touched);
+    if (dirty && threadIdx.x == 0) {
+        // rows whose rates may have changed: the rows of the changed voxel(s) and of their 14 neighbours
+        int n = 0;
+        if (sh_ok) {
+            const int di[11] = {0, 1, 1, -1, -1, 0, 0, 2, -2, 0, 0}, dj[11] = {0, 1, -1, 1, -1, 1, -1, 0, 0, 2, -2};
+            for (int v = 0; v < (sh_ev.type == EV_DIFF ? 2 : 1); ++v) {
+                const int ci = v ? sh_ev.target[0] : sh_ev.pos[0], cj = v ? sh_ev.target[1] : sh_ev.pos[1];
+                for (int q = 0; q < 11; ++q) {
+                    const int i = ci + di[q], j = cj + dj[q];
+                    if (i < 0 || i >= L || j < 0 || j >= L) continue;
+                    const int e = (i << 16) | j;
+                    bool dup = false;
+                    for (int t = 1; t <= n; ++t) dup |= (dirty[t] == e);
+                    if (!dup && n < DIRTY_MAX) dirty[++n] = e;
+                }
+            }
+        }
+        dirty[0] = n;
+    }
 }
 
 // Direct apply (cetkmc_apply): everything decided by the host.  ONE 64-thread block.

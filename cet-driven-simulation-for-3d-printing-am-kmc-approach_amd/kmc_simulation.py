@@ -35,7 +35,7 @@ THERMAL_DT = 1e-6           # kmc_simulation.py:250
 _MAX_STREAM_DOUBLES = 1 << 25   # host staging cap for the pre-drawn NumPy stream (256 MiB)
 
 
-def _advance_to(engine, first, last, L, defect_fraction, rng_mode=0, seed=0):
+def _advance_to(engine, first, last, L, defect_fraction, rng_mode=0, seed=0, incremental=True):
     """Run steps first..last (inclusive) on the device.  Returns (steps_done, terminated,
     last_total, dt_sum_increments) with both host generators left where the reference's would be."""
     dts = []
@@ -52,7 +52,8 @@ def _advance_to(engine, first, last, L, defect_fraction, rng_mode=0, seed=0):
         np_state = np.random.get_state()
         u_np = np.random.random(n * per_step)
         res = engine.run_steps(step, n, defect_fraction, draws[:, 0], draws[:, 1] if per == 3 else None, u_np,
-                               rng_mode=rng_mode, seed=seed, thermal_mode=1, thermal_dt=THERMAL_DT)
+                               rng_mode=rng_mode, seed=seed, thermal_mode=1, thermal_dt=THERMAL_DT,
+                               incremental=incremental)
         done = res["done"]
         # rewind both generators to what the executed steps consumed
         np.random.set_state(np_state)
@@ -115,6 +116,7 @@ def run_kmc(
     *,
     checkpoint_every: int = 0,
     resume_from: str = None,
+    incremental: bool = True,
 ):
     """KMC microstructure evolution with natural defect injection (same contract as the
     reference).  ``defect_fraction`` is the per-event probability that the just-updated voxel
@@ -122,7 +124,9 @@ def run_kmc(
 
     Extensions (keyword-only, not in the reference): ``checkpoint_every=k`` writes
     ``outputs/<prefix>/checkpoint.npz`` every k steps; ``resume_from=path`` continues such a run --
-    the continued run is bit-identical to an uninterrupted one (lattice, time, CSV, RNG streams)."""
+    the continued run is bit-identical to an uninterrupted one (lattice, time, CSV, RNG streams);
+    ``incremental=False`` re-evaluates the whole lattice on every step like get_event_rates does (the
+    default re-evaluates only the rows an event made stale between temperature updates -- same results)."""
     import cetkmc
 
     output_dir = f"outputs/{output_prefix}"
@@ -167,7 +171,7 @@ def run_kmc(
         stop = min(stop, n_steps - 1)
         if checkpoint_every > 0:      # also stop right before every checkpoint boundary
             stop = min(stop, (next_step // checkpoint_every + 1) * checkpoint_every - 1)
-        done, terminated, last_total, dts = _advance_to(engine, next_step, stop, L, defect_fraction)
+        done, terminated, last_total, dts = _advance_to(engine, next_step, stop, L, defect_fraction, incremental=incremental)
         for dt in dts:
             total_time += dt
         if terminated:

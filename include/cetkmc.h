@@ -100,6 +100,10 @@ typedef struct cetkmc_run_args {
     int64_t n_q;
     int32_t use_latent;       /* thermal_mode 2: latent-heat term on/off                */
     int32_t profile;          /* 1: time every rate-sweep launch with hipEvents         */
+    int32_t incremental;      /* 0: every step evaluates the whole lattice (get_event_rates, kmc_event_rates.py:162);
+                                 1: exact incremental mode -- between temperature updates only the rows whose
+                                    rates the previous event can have changed are re-evaluated (identical
+                                    results: the canonical summation tree is rebuilt from the same row sums) */
 } cetkmc_run_args;
 
 typedef struct cetkmc_run_result {
@@ -111,6 +115,7 @@ typedef struct cetkmc_run_result {
     double  sweep_ms_total;   /* profile: sum of rate-sweep kernel durations            */
     int64_t sweep_launches;
     double  wall_ms;          /* device time of the whole call (hipEvents on the stream) */
+    int64_t full_sweeps;      /* steps that evaluated the whole lattice (= steps issued unless incremental) */
 } cetkmc_run_result;
 
 const char* cetkmc_last_error(void);

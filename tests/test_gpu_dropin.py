@@ -17,8 +17,9 @@ TRAJ = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "
 EVENTS = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "events_*.npz")))
 
 
+@pytest.mark.parametrize("incremental", [True, False])
 @pytest.mark.parametrize("name", TRAJ)
-def test_run_kmc_matches_reference(name, tmp_path, monkeypatch, capsys):
+def test_run_kmc_matches_reference(name, incremental, tmp_path, monkeypatch, capsys):
     """kmc_simulation.run_kmc: same return tuple, metrics.csv, prints and RNG end state as the
     reference run the fixture was recorded from (kmc_simulation.py:203-398)."""
     import kmc_simulation
@@ -28,7 +29,9 @@ def test_run_kmc_matches_reference(name, tmp_path, monkeypatch, capsys):
               n_seeds=int(z["n_seeds"]), impurity_c=float(z["impurity_c"]), output_prefix=name)
     if float(z["temp"]) == int(z["temp"]):
         kw["temp"] = int(z["temp"])
-    state, atom_type, total_time, theta, phi = kmc_simulation.run_kmc(**kw)
+    if int(z["L"]) >= 30 and not incremental:
+        pytest.skip("large cases run once (default mode)")
+    state, atom_type, total_time, theta, phi = kmc_simulation.run_kmc(**kw, incremental=incremental)
     assert state.dtype == np.int64 and theta.dtype == np.float64
     assert np.array_equal(state, z["final_state"]) and np.array_equal(atom_type, state)
     assert np.array_equal(theta, z["final_theta"]) and np.array_equal(phi, z["final_phi"])

@@ -469,3 +469,52 @@ def test_stream_kernel_four_row_blocks(L, monkeypatch):
         out.append((e.rate_sweep(),) + e.row_sums())
     assert out[0][0] == out[1][0]
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+
+
+@pytest.mark.parametrize("L,fill,n_slabs,thermal", [(20, 0.25, 1, 1), (40, 0.2, 3, 1), (33, 0.6, 1, 0), (70, 0.1, 2, 1)])
+def test_incremental_mode_bit_identical(L, fill, n_slabs, thermal):
+    """incremental=1 (only the rows an event made stale are re-evaluated between temperature updates)
+    is exact: totals, chosen events, counts, row sums and all fields equal the full-sweep run bit for bit."""
+    state, theta, phi, T, defects = random_lattice(L, 41 + L, fill=fill)
+    rs = np.random.RandomState(8)
+    n = 130
+    u_pick, u_def, u_np = rs.random_sample(n), rs.random_sample(n), rs.random_sample(n * (L * L + 2))
+    outs = []
+    for inc, ns in ((False, 1), (True, n_slabs)):
+        e = _engine(L, 0.2, n_slabs=ns)
+        e.upload(state, theta, phi, T, defects)
+        res = e.run_steps(3, n, 0.05, u_pick, u_def, u_np, rng_mode=0, thermal_mode=thermal, incremental=inc)
+        assert res["done"] == n
+        n_full = n if not inc else 1 + (sum(1 for s in range(1, n) if (3 + s) % 20 == 0) if thermal else 0)
+        assert res["full_sweeps"] == n_full
+        d = e.download(defects=True)
+        info = e.rate_sweep()
+        outs.append((res["totals"].tobytes(), res["events"].tobytes(), res["n_events"].tobytes(), res["np_used"], info,
+                     e.row_sums()[0].tobytes(), e.row_sums()[1].tobytes()) + tuple(d[k].tobytes() for k in sorted(d)))
+        e.close()
+    assert outs[0] == outs[1]
+
+
+def test_incremental_mode_large_rows_and_laser():
+    """Incremental stepping with two 256-voxel chunks per row (L > 256), the laser thermal mode and the
+    counter-hash species draw."""
+    import cetkmc
+    from cetkmc import synthetic
+    L = 264
+    st, th, ph, T, df = synthetic.planes(L, 0, L, seed=3)
+    rs = np.random.RandomState(9)
+    idx = rs.randint(0, L, (4000, 3))
+    st[idx[:, 0], idx[:, 1], idx[:, 2]] = rs.randint(1, 5, 4000)
+    n = 45
+    q = synthetic.laser_planes(L, 0, n)
+    u_pick, u_def, u_np = rs.random_sample(n), rs.random_sample(n), rs.random_sample(2 * n + 2)
+    outs = []
+    for inc in (False, True):
+        e = cetkmc.Engine(L, impurity_c=0.2)
+        e.upload_planes(0, L, st, th, ph, T, df)
+        e.set_prev_state(None)
+        r = e.run_steps(0, n, 3e-3, u_pick, u_def, u_np, rng_mode=1, seed=5, thermal_mode=2, q_planes=q, incremental=inc)
+        assert r["done"] == n
+        outs.append((r["totals"].tobytes(), r["events"].tobytes(), e.rate_sweep(), e.row_sums()[0].tobytes()))
+        e.close()
+    assert outs[0] == outs[1]
