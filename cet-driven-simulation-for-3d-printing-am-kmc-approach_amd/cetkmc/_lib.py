@@ -44,6 +44,14 @@ class RunArgs(C.Structure):
     ]
 
 
+class SuperArgs(C.Structure):
+    _fields_ = [
+        ("step0", C.c_int64), ("n_steps", C.c_int64), ("box", C.c_int32), ("defect_fraction", C.c_double),
+        ("seed", C.c_uint64), ("thermal_mode", C.c_int32), ("thermal_dt", C.c_double),
+        ("q_planes", C.POINTER(C.c_double)), ("n_q", C.c_int64), ("use_latent", C.c_int32),
+    ]
+
+
 class RunResult(C.Structure):
     _fields_ = [
         ("steps_done", C.c_int64), ("status", C.c_int32), ("np_used", C.c_int64), ("q_used", C.c_int64),
@@ -80,6 +88,7 @@ PROTOTYPES = {
     "cetkmc_enumerate_events": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _P(C.c_int64)]),
     "cetkmc_row_sums": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cetkmc_run_steps": (C.c_int, [C.c_void_p, _P(RunArgs), _P(RunResult), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cetkmc_run_supersteps": (C.c_int, [C.c_void_p, _P(SuperArgs), _P(RunResult), C.c_void_p, C.c_void_p, C.c_void_p]),
     "cetkmc_cluster": (C.c_int, [C.c_void_p, C.c_double, _P(C.c_int64)]),
     "cetkmc_cluster_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cetkmc_cluster_labels": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import Event, Params, RunArgs, RunResult, SweepInfo, build_library  # noqa: F401
+from ._lib import Event, Params, RunArgs, RunResult, SuperArgs, SweepInfo, build_library  # noqa: F401
 
 EVENT_DTYPE = np.dtype([("type", "<i4"), ("pos", "<i4", 3), ("target", "<i4", 3), ("atom", "<i4"),
                         ("rate", "<f8"), ("dep_rank", "<i8"), ("theta", "<f8"), ("phi", "<f8")], align=True)
@@ -252,6 +252,25 @@ class Engine:
         if want_logs:
             out.update(totals=totals[:done + (1 if res.status == 1 else 0)], events=events[:done], n_events=nev[:done])
         return out
+
+    # -- Mode B: synchronous super-steps over (L/box)^3 boxes (not in the reference; include/cetkmc.h) --------
+    def run_supersteps(self, step0, n, box, defect_fraction, seed, thermal_mode=1, thermal_dt=1e-6, q_planes=None,
+                       use_latent=True, want_events=False):
+        a = SuperArgs()
+        q = None if q_planes is None else np.ascontiguousarray(q_planes, dtype=np.float64)
+        a.step0, a.n_steps, a.box, a.defect_fraction, a.seed = int(step0), int(n), int(box), float(defect_fraction), int(seed)
+        a.thermal_mode, a.thermal_dt = int(thermal_mode), float(thermal_dt)
+        a.q_planes, a.n_q, a.use_latent = _dptr(q), (0 if q is None else q.shape[0]), int(bool(use_latent))
+        D = (self.L // int(box)) ** 3 if box and self.L % int(box) == 0 else 1
+        res = RunResult()
+        totals = np.zeros(n + 1, np.float64)
+        n_exec = np.zeros(max(n, 1), np.int64)
+        events = np.zeros((max(n, 1), D), dtype=EVENT_DTYPE) if want_events else None
+        self._ck(self.lib.cetkmc_run_supersteps(self.h, C.byref(a), C.byref(res), _ptr(totals), _ptr(events), _ptr(n_exec)))
+        done = int(res.steps_done)
+        return dict(done=done, status=int(res.status), q_used=int(res.q_used), nucleation_count=int(res.nucleation_count),
+                    wall_ms=res.wall_ms, totals=totals[:done + (1 if res.status == 1 else 0)], n_exec=n_exec[:done],
+                    events=None if events is None else events[:done], domains=D)
 
     # -- grain clustering (utils.get_clusters on the device) --------------------------------------
     def clusters(self, threshold=0.5, labels=False):

@@ -17,6 +17,7 @@
 
 #include "kernels.hpp"
 #include "cluster.hpp"
+#include "superstep.hpp"
 
 using namespace cetkmc;
 
@@ -1039,6 +1040,97 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
     if (totals && ss.status == 1 && nt <= n) totals[done] = ss.total;
     if (events && done > 0) HIPCHK(hipMemcpy(events, h->d_log_event, (size_t)done * sizeof(cetkmc_event), hipMemcpyDeviceToHost));
     if (n_events && done > 0) HIPCHK(hipMemcpy(n_events, h->d_log_nev, (size_t)done * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- Mode B: synchronous super-steps over spatial boxes (superstep.hpp) ------------------------------
+int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_result* res, double* totals,
+                          cetkmc_event* events, int64_t* n_executed)
+{
+    Handle* h = (Handle*)handle;
+    if (!h || !a || !res) return fail("null argument");
+    const int64_t n = a->n_steps;
+    if (n < 0) return fail("n_steps < 0");
+    if (h->comm && h->nranks > 1) return fail("cetkmc_run_supersteps: single process only");
+    if (h->sweep_variant != 1) return fail("cetkmc_run_supersteps needs sweep_variant 1");
+    if (a->box < 8 || a->box > 16 || (a->box & 1) || h->L % a->box) return fail("box must be even, 8..16, and divide L");
+    int64_t n_therm = 0;
+    if (a->thermal_mode) for (int64_t s = 0; s < n; ++s) if ((a->step0 + s) % 20 == 0) ++n_therm;
+    if (a->thermal_mode == 2 && (n_therm > a->n_q || (n_therm > 0 && !a->q_planes)))
+        return fail("thermal_mode 2 needs one q plane per thermal update in the batch");
+    HIPCHK(hipSetDevice(h->dev));
+    const size_t L2 = (size_t)h->L * h->L;
+    SuperCfg C{};
+    C.step0 = a->step0; C.defect_fraction = a->defect_fraction; C.seed = a->seed;
+    C.box = a->box; C.H = a->box / 2; C.nb = h->L / a->box;
+    C.PH = 1; while (C.PH < C.H) C.PH <<= 1;
+    C.PT = 1; while (C.PT < 3 * C.H) C.PT <<= 1;
+    const int D = C.nb * C.nb * C.nb;
+    const size_t shmem = (size_t)C.PT * C.PH * C.PH * 18;
+    {
+        size_t c1 = h->cap_steps, c2 = h->cap_steps, c3 = h->cap_steps, c4 = h->cap_steps, c5 = h->cap_steps;
+        CHK(grow(&h->d_u_pick, &c1, (size_t)n));
+        CHK(grow(&h->d_u_defect, &c2, (size_t)n));
+        CHK(grow(&h->d_log_total, &c3, (size_t)n));
+        CHK(grow(&h->d_log_event, &c4, (size_t)n));
+        CHK(grow(&h->d_log_nev, &c5, (size_t)n));
+        h->cap_steps = std::min({c1, c2, c3, c4, c5});
+        if (a->thermal_mode == 2) CHK(grow(&h->d_q, &h->cap_q, (size_t)std::max<int64_t>(n_therm, 1) * L2));
+    }
+    cetkmc_event* d_dom = nullptr;
+    int* d_mk = nullptr;
+    unsigned long long* d_cnt = nullptr;
+    cetkmc_event* d_log = nullptr;
+    HIPCHK(hipMalloc((void**)&d_dom, (size_t)D * sizeof(cetkmc_event)));
+    HIPCHK(hipMalloc((void**)&d_mk, (size_t)D * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&d_cnt, 2 * sizeof(unsigned long long)));
+    if (events && n > 0) HIPCHK(hipMalloc((void**)&d_log, (size_t)n * D * sizeof(cetkmc_event)));
+    HIPCHK(hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), h->stream));
+    if (a->thermal_mode == 2 && n_therm > 0)
+        HIPCHK(hipMemcpyAsync(h->d_q, a->q_planes, (size_t)n_therm * L2 * 8, hipMemcpyHostToDevice, h->stream));
+    StepState ss;
+    HIPCHK(hipMemcpyAsync(&ss, h->d_ss, sizeof ss, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    ss.cur = 0; ss.status = 0; ss.np_pos = 0; ss.q_pos = 0;
+    HIPCHK(hipMemcpyAsync(h->d_ss, &ss, sizeof ss, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    BatchCfg cfg{};
+    cfg.step0 = a->step0; cfg.np_cap = 0; cfg.defect_fraction = a->defect_fraction; cfg.seed = a->seed;
+    cfg.rng_mode = 1; cfg.batch = 1;
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    int64_t q_idx = 0;
+    for (int64_t s = 0; s < n; ++s) {
+        const int64_t g = a->step0 + s;
+        if (a->thermal_mode && g % 20 == 0) {
+            if (a->thermal_mode == 1) CHK(launch_thermal(h, a->thermal_dt, 0, nullptr, 0, 1, true));
+            else { CHK(launch_thermal(h, a->thermal_dt, 1, h->d_q + (size_t)q_idx * L2, a->use_latent, 1, true)); ++q_idx; }
+        }
+        CHK(launch_sweep(h, true));
+        CHK(launch_select(h, cfg, 0.0, 1));                 // total, counts, termination test
+        hipLaunchKernelGGL(k_domain_select, dim3(D), dim3(64), shmem, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
+                           (int)h->slabs.size(), h->L, C, (const StepState*)h->d_ss, (const double*)h->d_ktab, d_dom, d_mk);
+        hipLaunchKernelGGL(k_domain_apply, dim3((D + 255) / 256), dim3(256), 0, h->stream, (const SlabView*)h->d_views[h->cur],
+                           (int)h->slabs.size(), D, (const cetkmc_event*)d_dom, (const int*)d_mk, h->d_ss, d_cnt, d_log);
+        hipLaunchKernelGGL(k_domain_touch, dim3(D), dim3(64), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
+                           (int)h->slabs.size(), (const cetkmc_event*)d_dom, (const StepState*)h->d_ss, (const double*)h->d_ktab);
+        hipLaunchKernelGGL(k_super_commit, dim3(1), dim3(1), 0, h->stream, h->d_ss, d_cnt, h->d_log_total, h->d_log_nev);
+        h->swept = false;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipMemcpyAsync(&ss, h->d_ss, sizeof ss, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    res->steps_done = ss.cur; res->status = ss.status; res->np_used = 0; res->q_used = q_idx;
+    res->nucleation_count = ss.nuc_count;
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    res->wall_ms = ms; res->sweep_ms_total = 0.0; res->sweep_launches = 0; res->full_sweeps = n;
+    const int64_t done = ss.cur;
+    if (totals && done > 0) HIPCHK(hipMemcpy(totals, h->d_log_total, (size_t)done * 8, hipMemcpyDeviceToHost));
+    if (totals && ss.status == 1 && done < n) totals[done] = ss.total;
+    if (n_executed && done > 0) HIPCHK(hipMemcpy(n_executed, h->d_log_nev, (size_t)done * 8, hipMemcpyDeviceToHost));
+    if (events && done > 0) HIPCHK(hipMemcpy(events, d_log, (size_t)done * D * sizeof(cetkmc_event), hipMemcpyDeviceToHost));
+    (void)hipFree(d_dom); (void)hipFree(d_mk); (void)hipFree(d_cnt); (void)hipFree(d_log);
     return 0;
 }
 

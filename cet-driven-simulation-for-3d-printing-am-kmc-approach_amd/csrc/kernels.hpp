@@ -643,7 +643,10 @@ __device__ __forceinline__ void ifc_append(const SlabView& S, int lp, int j, int
 {
     const int64_t t = S.tidx(lp + 2, j, k);
     if (S.ifc_in[t]) return;
-    S.ifc_in[t] = 1;
+    // test-and-set on the byte through its 32-bit word: several waves may touch the same voxel (Mode B)
+    unsigned* w = reinterpret_cast<unsigned*>(S.ifc_in + (t & ~(int64_t)3));
+    const unsigned bit = 1u << (8 * (int)(t & 3));
+    if (atomicOr(w, bit) & bit) return;
     const int pos = atomicAdd(S.ifc_n, 1);
     S.ifc_list[pos] = ((unsigned)lp << 20) | ((unsigned)j << 10) | (unsigned)k;
 }

@@ -118,6 +118,24 @@ typedef struct cetkmc_run_result {
     int64_t full_sweeps;      /* steps that evaluated the whole lattice (= steps issued unless incremental) */
 } cetkmc_run_result;
 
+/* Mode B -- synchronous super-steps (NOT in the reference; SURVEY.md section 8(f)4, DESIGN.md "Mode B").
+ * The lattice is tiled by (L/box)^3 cubic boxes; every super-step runs the ordinary full rate sweep and then
+ * every box executes at most one event picked from its active octant (octant = step % 8), so several thousand
+ * events are executed per sweep.  box: even, 8..16, divides L.  All uniforms are counter based (seed, step, key).
+ * The trajectory is not the reference's; its bit-exact comparator is the oracle's orc_run_supersteps. */
+typedef struct cetkmc_super_args {
+    int64_t step0;            /* global index of the first super-step (thermal cadence step%20, octant step%8) */
+    int64_t n_steps;
+    int32_t box;
+    double  defect_fraction;
+    uint64_t seed;
+    int32_t thermal_mode;     /* as cetkmc_run_args */
+    double  thermal_dt;
+    const double* q_planes;
+    int64_t n_q;
+    int32_t use_latent;
+} cetkmc_super_args;
+
 const char* cetkmc_last_error(void);
 int cetkmc_abi_version(void);
 int cetkmc_device_count(int* n);
@@ -182,6 +200,11 @@ int cetkmc_row_sums(void* handle, double* rowsum, int32_t* rowcnt);
  * (each [n_steps], may be NULL) receive the per-step total rate, chosen event and len(events). */
 int cetkmc_run_steps(void* handle, const cetkmc_run_args* args, cetkmc_run_result* res,
                      double* totals, cetkmc_event* events, int64_t* n_events);
+
+/* totals[n] (Mode A total of every super-step's sweep), events[n][D] or NULL (type -1: idle box),
+ * n_executed[n] events applied per super-step.  res->np_used is 0; single process only. */
+int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_result* res, double* totals,
+                          cetkmc_event* events, int64_t* n_executed);
 
 /* Grain clustering on the device (utils.get_clusters / dfs_cluster, utils.py:28-84): connected
  * components of occupied 14-stencil neighbours with misorientation < threshold, numbered 1.. in the

@@ -601,5 +601,159 @@ int64_t orc_run_steps(const orc_params *P, int L, int8_t *state, double *theta, 
     return s;
 }
 
+/* ---- Mode B: synchronous super-steps over spatial domains ---------------------------
+ * NOT in the reference (which executes one event per full-lattice sweep, kmc_simulation.py:246-332).
+ * Definition (DESIGN.md "Mode B"); this function is its bit-exact comparator.
+ *   - the lattice is tiled by nb^3 cubic boxes of edge `box` (even, >= 8, divides L); box d =
+ *     (di*nb + dj)*nb + dk.  Super-step g activates one octant of every box: sector = g % 8,
+ *     (si,sj,sk) = bits 2,1,0; window of box d = [di*box + si*H, +H) x ... with H = box/2.  Active
+ *     windows of different boxes are >= H+1 >= 5 voxels apart on some axis, events write within +-2
+ *     of their voxel, so the events of one super-step never touch the same voxel.
+ *     box == L is the single-domain case: window = whole lattice, no sectors, identical to one
+ *     Mode A step driven by the same uniforms.
+ *   - all rates of a super-step are evaluated on the lattice as it was at the start (after the thermal
+ *     update, same step%20 cadence as kmc_simulation.py:248-250); totals[g] is the Mode A total.
+ *   - every box picks at most one event from its window: the window's events in the reference order
+ *     (plane i; dep | diff | empty block; j; k; slot) summed by the canonical tree restricted to the
+ *     window (k padded to pow2(H), j likewise, 3H blocks padded to a power of two), r = u_pick * R_d, same
+ *     descent rule and slot scan as Mode A.  A box whose window holds no events (or R_d < 1e-25 / not
+ *     finite) is idle (event type -1).
+ *   - uniforms are counter based: u(seed, g, key): pick KEY 1<<40 | d, theta 2<<40 | d, phi 3<<40 | d,
+ *     defect 4<<40 | d, deposition species j*L + k (as Mode A rng_mode 1).
+ *   - all picked events are applied (kmc_simulation.py:276-327 each), box order.
+ * events: [n][D] (type -1 for idle boxes) or NULL; n_exec[n] = events applied per super-step. */
+#define KEY_PICK   (1ULL << 40)
+#define KEY_THETA  (2ULL << 40)
+#define KEY_PHI    (3ULL << 40)
+#define KEY_DEFECT (4ULL << 40)
+
+static int window_select(const orc_params *P, int L, const int8_t *state, const double *theta,
+                         const double *phi, const double *T, const int8_t *defects,
+                         int i0, int j0, int k0, int H, double u, double *leaf, int32_t *lcnt,
+                         orc_event *ev)
+{
+    const int PH = next_pow2(H), PT = next_pow2(3 * H);
+    const int64_t NL = (int64_t)PT * PH * PH;
+    memset(leaf, 0, sizeof(double) * (size_t)NL);
+    memset(lcnt, 0, sizeof(int32_t) * (size_t)NL);
+    slots_t S;
+    int64_t n = 0;
+    for (int ii = 0; ii < H; ++ii)
+        for (int c = 0; c < 3; ++c)
+            for (int jj = 0; jj < H; ++jj)
+                for (int kk = 0; kk < H; ++kk) {
+                    voxel_slots(P, L, state, theta, phi, T, defects, i0 + ii, j0 + jj, k0 + kk, c, &S);
+                    double s = 0.0;
+                    for (int m = 0; m < S.n; ++m) s += S.rate[m];
+                    const int64_t q = ((int64_t)(3 * ii + c) * PH + jj) * PH + kk;
+                    leaf[q] = s; lcnt[q] = S.n;
+                    n += S.n;
+                }
+    memset(ev, 0, sizeof *ev);
+    ev->type = -1;                                   /* idle box: pos 0, target -1, rate 0 */
+    ev->target[0] = ev->target[1] = ev->target[2] = -1;
+    ev->dep_rank = -1;
+    if (n == 0) return 1;
+    const double R = tree_sum(leaf, 0, NL, NL);
+    if (R < 1e-25 || !isfinite(R)) return 1;
+    const double r = u * R;
+    double base = 0.0;
+    const int64_t q = descend(leaf, NULL, lcnt, NL, NL, &base, r);
+    const int kk = (int)(q % PH), jj = (int)((q / PH) % PH), b = (int)(q / ((int64_t)PH * PH));
+    const int i = i0 + b / 3, c = b % 3, j = j0 + jj, k = k0 + kk;
+    voxel_slots(P, L, state, theta, phi, T, defects, i, j, k, c, &S);
+    int pick = S.n - 1;
+    double cum = base;
+    for (int m = 0; m < S.n; ++m) {
+        cum += S.rate[m];
+        if (cum >= r) { pick = m; break; }
+    }
+    ev->type = S.type[pick];
+    ev->pos[0] = i; ev->pos[1] = j; ev->pos[2] = k;
+    memcpy(ev->target, S.target[pick], sizeof ev->target);
+    ev->rate = S.rate[pick];
+    ev->atom = S.atom[pick];
+    ev->dep_rank = -1;
+    return 0;
+}
+
+int64_t orc_run_supersteps(const orc_params *P, int L, int8_t *state, double *theta, double *phi,
+                           double *T, const int8_t *defects, int8_t *prev_state,
+                           int64_t step0, int64_t n, int box, double defect_fraction, uint64_t seed,
+                           int thermal_mode, double thermal_dt, const double *q_planes, int64_t *q_used,
+                           double *totals, orc_event *events, int64_t *n_exec,
+                           int64_t *nuc_count, int *status)
+{
+    const int64_t nv = (int64_t)L * L * L;
+    const int nb = L / box, H = (box == L) ? L : box / 2;
+    const int64_t D = (int64_t)nb * nb * nb;
+    const int PH = next_pow2(H), PT = next_pow2(3 * H);
+    const int64_t NL = (int64_t)PT * PH * PH;
+    double *rowsum = (double *)malloc(sizeof(double) * 3 * (size_t)L * L);
+    int32_t *rowcnt = (int32_t *)malloc(sizeof(int32_t) * 3 * (size_t)L * L);
+    double *blocksum = (double *)malloc(sizeof(double) * 3 * (size_t)L);
+    int64_t *blockcnt = (int64_t *)malloc(sizeof(int64_t) * 3 * (size_t)L);
+    double *Tn = (double *)malloc(sizeof(double) * (size_t)nv);
+    double *leaf = (double *)malloc(sizeof(double) * (size_t)NL);
+    int32_t *lcnt = (int32_t *)malloc(sizeof(int32_t) * (size_t)NL);
+    orc_event *picked = (orc_event *)malloc(sizeof(orc_event) * (size_t)D);
+    int64_t qpos = 0, s = 0;
+    *status = 0;
+    for (; s < n; ++s) {
+        const int64_t g = step0 + s;
+        if (thermal_mode && g % 20 == 0) {
+            if (thermal_mode == 1) {
+                orc_thermal_cet(P, L, T, thermal_dt, 1, Tn);
+            } else {
+                orc_thermal_laser(P, L, T, state, prev_state, thermal_dt, q_planes + qpos * (int64_t)L * L, 1, Tn);
+                memcpy(prev_state, state, (size_t)nv);
+                ++qpos;
+            }
+            memcpy(T, Tn, sizeof(double) * (size_t)nv);
+        }
+        orc_row_sums(P, L, state, theta, phi, T, defects, 0, L, rowsum, rowcnt);
+        orc_block_sums(L, rowsum, rowcnt, 0, L, blocksum, blockcnt);
+        int64_t ne = 0, nd = 0;
+        const double total = orc_total(L, blocksum, blockcnt, &ne, &nd);
+        totals[s] = total;
+        if (ne == 0 || total < 1e-25 || !isfinite(total)) { *status = 1; break; }
+        const int sec = (int)(g % 8), si = (sec >> 2) & 1, sj = (sec >> 1) & 1, sk = sec & 1;
+        /* select every box's event on the frozen lattice ... */
+        for (int64_t d = 0; d < D; ++d) {
+            const int di = (int)(d / ((int64_t)nb * nb)), dj = (int)((d / nb) % nb), dk = (int)(d % nb);
+            const int i0 = (box == L) ? 0 : di * box + si * H;
+            const int j0 = (box == L) ? 0 : dj * box + sj * H;
+            const int k0 = (box == L) ? 0 : dk * box + sk * H;
+            const double u = orc_counter_uniform(seed, (uint64_t)g, KEY_PICK | (uint64_t)d);
+            window_select(P, L, state, theta, phi, T, defects, i0, j0, k0, H, u, leaf, lcnt, &picked[d]);
+        }
+        /* ... then apply them all */
+        int64_t ex = 0;
+        for (int64_t d = 0; d < D; ++d) {
+            orc_event *ev = &picked[d];
+            if (events) events[s * D + d] = *ev;
+            if (ev->type < 0) continue;
+            if (ev->type == EV_DEP) {
+                const double u = orc_counter_uniform(seed, (uint64_t)g, (uint64_t)ev->pos[1] * (uint64_t)L + (uint64_t)ev->pos[2]);
+                ev->atom = dep_species(P, u);
+                if (events) events[s * D + d].atom = ev->atom;
+            }
+            double th = 0.0, ph = 0.0;
+            if (ev->type == EV_DEP || ev->type == EV_NUC) {
+                th = 0.0 + (3.141592653589793 - 0.0) * orc_counter_uniform(seed, (uint64_t)g, KEY_THETA | (uint64_t)d);
+                ph = 0.0 + (6.283185307179586 - 0.0) * orc_counter_uniform(seed, (uint64_t)g, KEY_PHI | (uint64_t)d);
+            }
+            const int mk = (defect_fraction > 0.0 &&
+                            orc_counter_uniform(seed, (uint64_t)g, KEY_DEFECT | (uint64_t)d) < defect_fraction) ? 1 : 0;
+            *nuc_count += orc_apply(L, state, theta, phi, ev, th, ph, mk);
+            ++ex;
+        }
+        if (n_exec) n_exec[s] = ex;
+    }
+    if (q_used) *q_used = qpos;
+    free(rowsum); free(rowcnt); free(blocksum); free(blockcnt); free(Tn); free(leaf); free(lcnt); free(picked);
+    return s;
+}
+
 int orc_sizeof_params(void) { return (int)sizeof(orc_params); }
 int orc_sizeof_event(void) { return (int)sizeof(orc_event); }

@@ -102,6 +102,7 @@ def lib():
         L.orc_select_sequential.restype = C.c_int64
         L.orc_total.restype = C.c_double
         L.orc_run_steps.restype = C.c_int64
+        L.orc_run_supersteps.restype = C.c_int64
         L.orc_counter_uniform.restype = C.c_double
         L.orc_counter_uniform.argtypes = [C.c_uint64] * 3
         _lib = L
@@ -258,6 +259,29 @@ class Lattice:
                     n_events=nev[:done])
 
 
+    # Mode B (not in the reference): synchronous super-steps over nb^3 boxes, see cet_oracle.c
+    def run_supersteps(self, step0, n, box, defect_fraction, seed, thermal_mode=1, thermal_dt=1e-6, q_planes=None,
+                       want_events=True):
+        L = self.L
+        D = (L // box) ** 3
+        totals = np.zeros(n, np.float64)
+        events = np.zeros((n, D), dtype=EVENT_DTYPE) if want_events else None
+        n_exec = np.zeros(n, np.int64)
+        q_used, nuc, status = C.c_int64(0), C.c_int64(self.nuc_count), C.c_int(0)
+        q = _f8(q_planes) if q_planes is not None else None
+        done = lib().orc_run_supersteps(
+            C.byref(self.params), L, _p(self.state, C.c_int8), _p(self.theta, C.c_double), _p(self.phi, C.c_double),
+            _p(self.T, C.c_double), _p(self.defects, C.c_int8), _p(self.prev_state, C.c_int8),
+            C.c_int64(step0), C.c_int64(n), int(box), C.c_double(defect_fraction), C.c_uint64(seed),
+            int(thermal_mode), C.c_double(thermal_dt), _p(q, C.c_double), C.byref(q_used), _p(totals, C.c_double),
+            events.ctypes.data_as(C.c_void_p) if want_events else None, _p(n_exec, C.c_int64), C.byref(nuc),
+            C.byref(status))
+        self.nuc_count = nuc.value
+        return dict(done=int(done), status=status.value, q_used=q_used.value,
+                    totals=totals[:max(done, 0) + (1 if status.value == 1 else 0)],
+                    events=None if events is None else events[:done], n_exec=n_exec[:done])
+
+
 def laser_source_plane(L, laser_pos, laser_power, beam_radius=50e-6, absorptivity=0.35):
     """thermal_solver.py:82-95: volumetric source of plane i=L-1 (I_surface / VOXEL_SIZE).
     Note the reference uses j0 for BOTH in-plane axes and ignores i0 (:86)."""
@@ -269,6 +293,9 @@ def laser_source_plane(L, laser_pos, laser_power, beam_radius=50e-6, absorptivit
     area_norm = np.pi * beam_radius * beam_radius
     I_surface = (laser_power * absorptivity / area_norm) * np.exp(-(r_m ** 2) / (beam_radius ** 2))
     return I_surface / VOXEL_SIZE
+
+
+KEY_PICK, KEY_THETA, KEY_PHI, KEY_DEFECT = 1 << 40, 2 << 40, 3 << 40, 4 << 40    # Mode B uniform keys
 
 
 def counter_uniform(seed, step, site):
