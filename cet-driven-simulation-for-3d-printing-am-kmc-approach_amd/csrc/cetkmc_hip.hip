@@ -218,8 +218,10 @@ int create_common(const cetkmc_params* p, int L, const std::vector<std::pair<int
     if (const char* e = getenv("CETKMC_STREAM_TJ")) h->stream_tj = (atoi(e) == 4) ? 4 : 8;
     h->shmem_stream = stream_lds(h->stream_tj);
     if (h->shmem_stream > 160 * 1024) { delete h; return fail("L too large for the LDS ring"); }
-    HIPCHK(hipFuncSetAttribute((const void*)k_sweep_stream<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds(8)));
-    HIPCHK(hipFuncSetAttribute((const void*)k_sweep_stream<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds(4)));
+    HIPCHK(hipFuncSetAttribute((const void*)k_sweep_stream<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds(8)));
+    HIPCHK(hipFuncSetAttribute((const void*)k_sweep_stream<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds(4)));
+    HIPCHK(hipFuncSetAttribute((const void*)k_sweep_stream<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds(8)));
+    HIPCHK(hipFuncSetAttribute((const void*)k_sweep_stream<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds(4)));
     h->dev = dev; h->G = G; h->my_first = my_first;
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
@@ -461,7 +463,8 @@ int launch_dirty_rows(Handle* h, hipEvent_t ev_a, hipEvent_t ev_b)
     return 0;
 }
 
-int launch_sweep(Handle* h, bool batch, hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr, bool skip_ifc = false)
+int launch_sweep(Handle* h, bool batch, hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr, bool skip_ifc = false,
+                 bool write_vox = false)
 {
     const int TR = SWEEP_TJ + 4;
     const size_t shmem0 = (size_t)((5 * TR * h->pitchS + 15) & ~15) + 225 * sizeof(double);
@@ -474,11 +477,15 @@ int launch_sweep(Handle* h, bool batch, hipEvent_t ev_a = nullptr, hipEvent_t ev
         if (h->sweep_variant == 1) {
             const StreamArgs sa = stream_args(h, v);
             const int nib = sa.group_count;
-            if (h->stream_tj == 8) {
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_stream<8>), dim3(nib * ((h->L + 7) / 8)), dim3(256), h->shmem_stream, h->stream, sa, h->d_ktab, ss);
-            } else {
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_stream<4>), dim3(nib * ((h->L + 3) / 4)), dim3(256), h->shmem_stream, h->stream, sa, h->d_ktab, ss);
-            }
+            const dim3 g8(nib * ((h->L + 7) / 8)), g4(nib * ((h->L + 3) / 4));
+            if (h->stream_tj == 8 && !write_vox)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_stream<8, false>), g8, dim3(256), h->shmem_stream, h->stream, sa, h->d_ktab, ss);
+            else if (h->stream_tj == 8)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_stream<8, true>), g8, dim3(256), h->shmem_stream, h->stream, sa, h->d_ktab, ss);
+            else if (!write_vox)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_stream<4, false>), g4, dim3(256), h->shmem_stream, h->stream, sa, h->d_ktab, ss);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_stream<4, true>), g4, dim3(256), h->shmem_stream, h->stream, sa, h->d_ktab, ss);
         } else {
             hipLaunchKernelGGL(k_sweep_simple, dim3(v.nloc * njt), dim3(256), shmem0, h->stream, h->kp, v, h->d_ktab, ss);
         }
@@ -1054,6 +1061,7 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
     if (h->comm && h->nranks > 1) return fail("cetkmc_run_supersteps: single process only");
     if (h->sweep_variant != 1) return fail("cetkmc_run_supersteps needs sweep_variant 1");
     if (a->box < 8 || a->box > 16 || (a->box & 1) || h->L % a->box) return fail("box must be even, 8..16, and divide L");
+    if ((int)h->slabs.size() > TOUCH_MAX_SLABS) return fail("cetkmc_run_supersteps: too many slabs");
     int64_t n_therm = 0;
     if (a->thermal_mode) for (int64_t s = 0; s < n; ++s) if ((a->step0 + s) % 20 == 0) ++n_therm;
     if (a->thermal_mode == 2 && (n_therm > a->n_q || (n_therm > 0 && !a->q_planes)))
@@ -1066,7 +1074,7 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
     C.PH = 1; while (C.PH < C.H) C.PH <<= 1;
     C.PT = 1; while (C.PT < 3 * C.H) C.PT <<= 1;
     const int D = C.nb * C.nb * C.nb;
-    const size_t shmem = (size_t)C.PT * C.PH * C.PH * 18;
+    const size_t shmem = (size_t)C.PT * C.PH * C.PH * 18;     // heap: 2*NL doubles + 2*NL flags
     {
         size_t c1 = h->cap_steps, c2 = h->cap_steps, c3 = h->cap_steps, c4 = h->cap_steps, c5 = h->cap_steps;
         CHK(grow(&h->d_u_pick, &c1, (size_t)n));
@@ -1078,11 +1086,11 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
         if (a->thermal_mode == 2) CHK(grow(&h->d_q, &h->cap_q, (size_t)std::max<int64_t>(n_therm, 1) * L2));
     }
     cetkmc_event* d_dom = nullptr;
-    int* d_mk = nullptr;
+    DomPick* d_picks = nullptr;
     unsigned long long* d_cnt = nullptr;
     cetkmc_event* d_log = nullptr;
     HIPCHK(hipMalloc((void**)&d_dom, (size_t)D * sizeof(cetkmc_event)));
-    HIPCHK(hipMalloc((void**)&d_mk, (size_t)D * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&d_picks, (size_t)D * sizeof(DomPick)));
     HIPCHK(hipMalloc((void**)&d_cnt, 2 * sizeof(unsigned long long)));
     if (events && n > 0) HIPCHK(hipMalloc((void**)&d_log, (size_t)n * D * sizeof(cetkmc_event)));
     HIPCHK(hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), h->stream));
@@ -1105,14 +1113,14 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
             if (a->thermal_mode == 1) CHK(launch_thermal(h, a->thermal_dt, 0, nullptr, 0, 1, true));
             else { CHK(launch_thermal(h, a->thermal_dt, 1, h->d_q + (size_t)q_idx * L2, a->use_latent, 1, true)); ++q_idx; }
         }
-        CHK(launch_sweep(h, true));
-        CHK(launch_select(h, cfg, 0.0, 1));                 // total, counts, termination test
-        hipLaunchKernelGGL(k_domain_select, dim3(D), dim3(64), shmem, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
-                           (int)h->slabs.size(), h->L, C, (const StepState*)h->d_ss, (const double*)h->d_ktab, d_dom, d_mk);
-        hipLaunchKernelGGL(k_domain_apply, dim3((D + 255) / 256), dim3(256), 0, h->stream, (const SlabView*)h->d_views[h->cur],
-                           (int)h->slabs.size(), D, (const cetkmc_event*)d_dom, (const int*)d_mk, h->d_ss, d_cnt, d_log);
-        hipLaunchKernelGGL(k_domain_touch, dim3(D), dim3(64), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
-                           (int)h->slabs.size(), (const cetkmc_event*)d_dom, (const StepState*)h->d_ss, (const double*)h->d_ktab);
+        CHK(launch_sweep(h, true, nullptr, nullptr, false, true));   // + per-voxel sums written back (all voxels)
+        CHK(launch_select(h, cfg, 0.0, 1));                          // total, counts, termination test
+        hipLaunchKernelGGL(k_domain_pick, dim3(D), dim3(64), shmem, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
+                           (int)h->slabs.size(), h->L, C, (const StepState*)h->d_ss, d_picks);
+        hipLaunchKernelGGL(k_domain_slot_apply, dim3((D + 63) / 64), dim3(64), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
+                           (int)h->slabs.size(), h->L, D, C, h->d_ss, (const DomPick*)d_picks, (const double*)h->d_ktab, d_dom, d_cnt, d_log);
+        hipLaunchKernelGGL(k_domain_touch, dim3((D + 7) / 8), dim3(256), 0, h->stream, (const SlabView*)h->d_views[h->cur],
+                           (int)h->slabs.size(), D, (const cetkmc_event*)d_dom, (const StepState*)h->d_ss);
         hipLaunchKernelGGL(k_super_commit, dim3(1), dim3(1), 0, h->stream, h->d_ss, d_cnt, h->d_log_total, h->d_log_nev);
         h->swept = false;
     }
@@ -1130,7 +1138,7 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
     if (totals && ss.status == 1 && done < n) totals[done] = ss.total;
     if (n_executed && done > 0) HIPCHK(hipMemcpy(n_executed, h->d_log_nev, (size_t)done * 8, hipMemcpyDeviceToHost));
     if (events && done > 0) HIPCHK(hipMemcpy(events, d_log, (size_t)done * D * sizeof(cetkmc_event), hipMemcpyDeviceToHost));
-    (void)hipFree(d_dom); (void)hipFree(d_mk); (void)hipFree(d_cnt); (void)hipFree(d_log);
+    (void)hipFree(d_dom); (void)hipFree(d_picks); (void)hipFree(d_cnt); (void)hipFree(d_log);
     return 0;
 }
 

@@ -208,8 +208,8 @@ struct StreamArgs {
     int L, gi0, nloc, RJ, pitchC, pitchT, Pk, group_first, group_count;
     const uint16_t* cls;
     const double* T;
-    const double* ifc_val;
-    const uint8_t* ifc_cnt;
+    double* ifc_val;          // read; written for non-interface voxels by the write-back instantiation (Mode B)
+    uint8_t* ifc_cnt;
     double* rowsum;
     int32_t* rowcnt;
 };
@@ -220,7 +220,9 @@ __device__ __forceinline__ unsigned alignbit16(unsigned hi, unsigned lo) { retur
 // rowsum/rowcnt.  `rowp(d, dj)` returns the class-row pointer (at k = 0) of plane li+d, row j+dj -- an LDS
 // ring slot in the streaming kernel, the global class array in the dirty-row kernel; everything else is
 // shared, so both produce bit-identical row sums.  `rp` = LDS scratch [3][STREAM_MAXCH] of this row.
-template <class ROWP>
+// WV (Mode B only): also store every non-interface voxel's EMPTY/DIFF category sum and count into ifc_val/ifc_cnt,
+// so that afterwards those arrays are valid for ALL owned voxels (interface voxels were written by k_interface).
+template <bool WV, class ROWP>
 __device__ __forceinline__ void sweep_row(const StreamArgs& A, const double* ktab, double* rp, ROWP rowp,
                                           int li, int lp, int j, bool top, int lane, int nch)
 {
@@ -285,9 +287,12 @@ __device__ __forceinline__ void sweep_row(const StreamArgs& A, const double* kta
                             if (rate > A.rate_threshold) { ev = rate; ++cemp; }   // <= I0: always finite
                         }
                     }
+                    if (WV && !(f & 0x0F00u) && k0 + h < L) { A.ifc_val[trow + h] = ev; A.ifc_cnt[trow + h] = (uint8_t)(ev != 0.0); }
                 } else if ((oc & 0x100u) && (f & 0x00F0u)) { // atom with empty neighbours
                     dv = A.ifc_val[trow + h];
                     cdiff += A.ifc_cnt[trow + h];
+                } else if (WV && k0 + h < L) {
+                    A.ifc_val[trow + h] = 0.0; A.ifc_cnt[trow + h] = 0;
                 }
                 if (!(h & 1)) { p0 = depv; p1 = dv; p2 = ev; }
                 else if (h == 1) { s0 = p0 + depv; s1 = p1 + dv; s2 = p2 + ev; }
@@ -322,7 +327,7 @@ __device__ __forceinline__ void sweep_row(const StreamArgs& A, const double* kta
     }
 }
 
-template <int TJ>
+template <int TJ, bool WV>
 __global__ __launch_bounds__(256) void k_sweep_stream(StreamArgs A, const double* __restrict__ ktab_g,
                                                       const StepState* __restrict__ ss)
 {
@@ -368,7 +373,7 @@ __global__ __launch_bounds__(256) void k_sweep_stream(StreamArgs A, const double
         for (int rr = 0; rr < TJ / 4; ++rr) {
             const int r = w + 4 * rr;
             auto rowp = [&](int d, int dj) { return ring + so[d + 2] + (r + 2 + dj) * pitchC + KOFFC; };
-            sweep_row(A, ktab, rowpart + r * 3 * STREAM_MAXCH, rowp, li, lp, j0 + r, top, lane, nch);
+            sweep_row<WV>(A, ktab, rowpart + r * 3 * STREAM_MAXCH, rowp, li, lp, j0 + r, top, lane, nch);
         }
         __syncthreads();   // ring slot (li-2)%5 is overwritten by the next plane's load
     }
@@ -397,7 +402,7 @@ __global__ __launch_bounds__(64) void k_rows_eval(StreamArgs A, const double* __
     const int li = lp + 2;
     const int nch = A.Pk > 256 ? (A.Pk >> 8) : 1;
     auto rowp = [&](int d, int dj) { return A.cls + ((int64_t)(li + d) * A.RJ + (j + 2 + dj)) * A.pitchC + KOFFC; };
-    sweep_row(A, ktab, rp, rowp, li, lp, j, A.gi0 + lp == A.L - 1, lane, nch);
+    sweep_row<false>(A, ktab, rp, rowp, li, lp, j, A.gi0 + lp == A.L - 1, lane, nch);
 }
 // block sums of the planes that own a dirty row (duplicates recompute the same value)
 __global__ __launch_bounds__(64) void k_plane_reduce_dirty(SlabView S, BlockEnt* __restrict__ blocks, const int* __restrict__ dirty,

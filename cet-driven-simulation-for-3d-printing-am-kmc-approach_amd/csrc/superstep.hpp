@@ -20,21 +20,24 @@ struct SuperCfg {
     int32_t nb;                 // boxes per axis
 };
 
-// One wave per box.  LDS: heap of NL = PT*PH*PH leaves (sums + has-events flags).
-__global__ __launch_bounds__(64) void k_domain_select(KParams P, const SlabView* __restrict__ slabs, int nslabs, int L,
-                                                      SuperCfg C, const StepState* __restrict__ ss,
-                                                      const double* __restrict__ ktab_g, cetkmc_event* __restrict__ dom_events,
-                                                      int* __restrict__ dom_defect)
+struct DomPick {          // result of the tree descent of one box
+    int32_t i, j, k, cat;  // cat < 0: idle box
+    double base, r;
+};
+
+// One wave per box: leaves = category sums of the window's voxels, LDS heap of NL = PT*PH*PH leaves, descent.
+// Runs after a sweep launched with write-back (k_sweep_stream<.., true>): ifc_val/ifc_cnt then hold the
+// EMPTY- or DIFF-category sum of EVERY owned voxel, so a leaf is two loads (dep leaves: one exp, top plane only).
+__global__ __launch_bounds__(64) void k_domain_pick(KParams P, const SlabView* __restrict__ slabs, int nslabs, int L,
+                                                    SuperCfg C, const StepState* __restrict__ ss, DomPick* __restrict__ picks)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ double ktab[226];
     const int lane = threadIdx.x;
     const int d = blockIdx.x;
     if (ss->status) return;
     const int NL = C.PT * C.PH * C.PH;
     double* hs = reinterpret_cast<double*>(smem);             // [2*NL]
     uint8_t* hf = reinterpret_cast<uint8_t*>(hs + 2 * NL);    // [2*NL]
-    for (int t = lane; t < 225; t += 64) ktab[t] = ktab_g[t];
     for (int q = lane; q < NL; q += 64) { hs[NL + q] = 0.0; hf[NL + q] = 0; }
     __syncthreads();
     const int64_t g = C.step0 + ss->cur;
@@ -42,40 +45,25 @@ __global__ __launch_bounds__(64) void k_domain_select(KParams P, const SlabView*
     const int H = C.H, nb = C.nb;
     const int di = d / (nb * nb), dj = (d / nb) % nb, dk = d % nb;
     const int i0 = di * C.box + ((sec >> 2) & 1) * H, j0 = dj * C.box + ((sec >> 1) & 1) * H, k0 = dk * C.box + (sec & 1) * H;
-
-    auto slab_of = [&](int i) { int sl = 0; for (int s = 0; s < nslabs; ++s) if (i >= slabs[s].gi0 && i < slabs[s].gi0 + slabs[s].nloc) sl = s; return sl; };
-
-    // ---- leaves: category sums of the window's voxels (frozen lattice) ----------------------
     for (int v = lane; v < H * H * H; v += 64) {
         const int kk = v % H, jj = (v / H) % H, ii = v / (H * H);
         const int i = i0 + ii, j = j0 + jj, k = k0 + kk;
-        const SlabView& S = slabs[slab_of(i)];
+        int sl = 0;
+        for (int s = 0; s < nslabs; ++s) if (i >= slabs[s].gi0 && i < slabs[s].gi0 + slabs[s].nloc) sl = s;
+        const SlabView& S = slabs[sl];
         const int li = i - S.gi0 + 2;
         const int st = S.state[S.sidx(li, j, k)];
         const int64_t t = S.tidx(li, j, k);
-        double sum[3] = {0.0, 0.0, 0.0};
-        int cnt[3] = {0, 0, 0};
-        if (S.ifc_in[t] && st < 128 && st != 4) {
-            // listed interface voxel: k_interface left its EMPTY- or DIFF-category sum in ifc_val
-            const int c = (st == 0) ? CAT_EMPTY : CAT_DIFF;
-            sum[c] = S.ifc_val[t]; cnt[c] = S.ifc_cnt[t];
-            if (st == 0 && i == L - 1) {
-                const double rate = dep_rate(P, pymax(S.T[t], 1.0));
-                if (finite_d(rate)) { sum[CAT_DEP] = rate; cnt[CAT_DEP] = 1; }
+        if (st >= 128 || st == 4) continue;
+        const int c = (st == 0) ? CAT_EMPTY : CAT_DIFF;
+        const int q = ((3 * ii + c) * C.PH + jj) * C.PH + kk;
+        hs[NL + q] = S.ifc_val[t]; hf[NL + q] = S.ifc_cnt[t] > 0;
+        if (st == 0 && i == L - 1) {
+            const double rate = dep_rate(P, pymax(S.T[t], 1.0));
+            if (finite_d(rate)) {
+                const int qd = ((3 * ii + CAT_DEP) * C.PH + jj) * C.PH + kk;
+                hs[NL + qd] = rate; hf[NL + qd] = 1;
             }
-        } else {
-            auto nbs = [&](int mm) -> int { return S.state[S.sidx(li + nbi_rt(mm), j + nbj_rt(mm), k + nbk_rt(mm))]; };
-            auto emit = [&](int cat, int, double rate, int, int) {
-                if (cat == CAT_DEP) { sum[0] += rate; ++cnt[0]; }
-                else if (cat == CAT_DIFF) { sum[1] += rate; ++cnt[1]; }
-                else { sum[2] += rate; ++cnt[2]; }
-            };
-            eval_voxel(P, S, ktab, li, i, j, k, st, S.T[t], nbs, emit);
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int q = ((3 * ii + c) * C.PH + jj) * C.PH + kk;
-            hs[NL + q] = sum[c]; hf[NL + q] = cnt[c] > 0;
         }
     }
     __syncthreads();
@@ -88,13 +76,8 @@ __global__ __launch_bounds__(64) void k_domain_select(KParams P, const SlabView*
         __syncthreads();
     }
     if (lane != 0) return;
-    // ---- pick (lane 0): tree descent, slot scan, uniforms ------------------------------------
-    cetkmc_event ev;
-    ev.type = -1;
-    ev.pos[0] = ev.pos[1] = ev.pos[2] = 0;
-    ev.target[0] = ev.target[1] = ev.target[2] = -1;
-    ev.atom = 0; ev.rate = 0.0; ev.dep_rank = -1; ev.theta = 0.0; ev.phi = 0.0;
-    int mk = 0;
+    DomPick pk;
+    pk.i = pk.j = pk.k = 0; pk.cat = -1; pk.base = 0.0; pk.r = 0.0;
     const double R = hs[1];
     if (hf[1] && !(R < 1e-25) && finite_d(R)) {
         const double r = counter_uniform(C.seed, (uint64_t)g, KEY_PICK | (uint64_t)d) * R;
@@ -106,12 +89,44 @@ __global__ __launch_bounds__(64) void k_domain_select(KParams P, const SlabView*
             else { base += hs[l]; n = l + 1; }
         }
         const int q = n - NL;
-        const int kk = q % C.PH, jj = (q / C.PH) % C.PH, b = q / (C.PH * C.PH);
-        const int i = i0 + b / 3, c = b % 3, j = j0 + jj, k = k0 + kk;
-        const SlabView& S = slabs[slab_of(i)];
+        const int b = q / (C.PH * C.PH);
+        pk.i = i0 + b / 3; pk.cat = b % 3; pk.j = j0 + (q / C.PH) % C.PH; pk.k = k0 + q % C.PH;
+        pk.base = base; pk.r = r;
+    }
+    picks[d] = pk;
+}
+
+// One thread per box: slot scan inside the chosen voxel, uniforms, lattice write (kmc_simulation.py:276-327).
+// Reads stay within +-2 of the chosen voxel and so do the writes of every other box's event (>= 5 away on
+// some axis): no box reads what another one writes, selection and application can share a kernel.
+__global__ __launch_bounds__(64) void k_domain_slot_apply(KParams P, const SlabView* __restrict__ slabs, int nslabs, int L, int D,
+                                                          SuperCfg C, StepState* ss, const DomPick* __restrict__ picks,
+                                                          const double* __restrict__ ktab_g, cetkmc_event* __restrict__ dom_events,
+                                                          unsigned long long* counters /* [0] executed, [1] nucleations */,
+                                                          cetkmc_event* log_events /* [n][D] or null */)
+{
+    __shared__ double ktab[226];
+    for (int t = threadIdx.x; t < 225; t += 64) ktab[t] = ktab_g[t];
+    __syncthreads();
+    if (ss->status) return;
+    const int d = blockIdx.x * 64 + threadIdx.x;
+    if (d >= D) return;
+    const int64_t g = C.step0 + ss->cur;
+    cetkmc_event ev;
+    ev.type = -1;
+    ev.pos[0] = ev.pos[1] = ev.pos[2] = 0;
+    ev.target[0] = ev.target[1] = ev.target[2] = -1;
+    ev.atom = 0; ev.rate = 0.0; ev.dep_rank = -1; ev.theta = 0.0; ev.phi = 0.0;
+    const DomPick pk = picks[d];
+    if (pk.cat >= 0) {
+        const int i = pk.i, j = pk.j, k = pk.k, c = pk.cat;
+        const double r = pk.r;
+        int sl = 0;
+        for (int s = 0; s < nslabs; ++s) if (i >= slabs[s].gi0 && i < slabs[s].gi0 + slabs[s].nloc) sl = s;
+        const SlabView& S = slabs[sl];
         const int li = i - S.gi0 + 2;
         const int st = S.state[S.sidx(li, j, k)];
-        double cum = base;
+        double cum = pk.base;
         bool found = false;
         int p_type = -1, p_m = -1, p_atom = 0;
         double p_rate = 0.0;
@@ -138,39 +153,65 @@ __global__ __launch_bounds__(64) void k_domain_select(KParams P, const SlabView*
             ev.theta = 0.0 + (3.141592653589793 - 0.0) * counter_uniform(C.seed, (uint64_t)g, KEY_THETA | (uint64_t)d);
             ev.phi = 0.0 + (6.283185307179586 - 0.0) * counter_uniform(C.seed, (uint64_t)g, KEY_PHI | (uint64_t)d);
         }
-        if (p_type >= 0)
-            mk = (C.defect_fraction > 0.0 && counter_uniform(C.seed, (uint64_t)g, KEY_DEFECT | (uint64_t)d) < C.defect_fraction) ? 1 : 0;
     }
     dom_events[d] = ev;
-    dom_defect[d] = mk;
-}
-
-// lattice writes of all picked events (one thread per box; the written voxels are pairwise distinct)
-__global__ __launch_bounds__(256) void k_domain_apply(const SlabView* __restrict__ slabs, int nslabs, int D,
-                                                      const cetkmc_event* __restrict__ dom_events, const int* __restrict__ dom_defect,
-                                                      StepState* ss, unsigned long long* counters /* [0] executed, [1] nucleations */,
-                                                      cetkmc_event* log_events /* [n][D] or null */)
-{
-    if (ss->status) return;
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= D) return;
-    const cetkmc_event ev = dom_events[d];
     if (log_events) log_events[ss->cur * (int64_t)D + d] = ev;
     if (ev.type < 0) return;
-    apply_event(slabs, nslabs, ev, dom_defect[d]);
+    const int mk = (C.defect_fraction > 0.0 && counter_uniform(C.seed, (uint64_t)g, KEY_DEFECT | (uint64_t)d) < C.defect_fraction) ? 1 : 0;
+    apply_event(slabs, nslabs, ev, mk);
     atomicAdd(&counters[0], 1ull);
     if (ev.type == EV_NUC) atomicAdd(&counters[1], 1ull);
 }
 
-// interface-list upkeep for the touched voxels, after ALL lattice writes of the super-step (one wave per box)
-__global__ __launch_bounds__(64) void k_domain_touch(KParams P, const SlabView* __restrict__ slabs, int nslabs,
-                                                     const cetkmc_event* __restrict__ dom_events, const StepState* __restrict__ ss,
-                                                     const double* __restrict__ ktab_g)
+// Interface-list upkeep for the touched voxels, after ALL lattice writes of the super-step.  8 boxes per
+// 256-thread block, 32 lanes per event (0..14 neighbourhood of the site, 16..30 of a diffusion target).  New
+// list entries are claimed by test-and-set on ifc_in and appended with ONE global atomic per block and slab.
+constexpr int TOUCH_MAX_SLABS = 64;
+__global__ __launch_bounds__(256) void k_domain_touch(const SlabView* __restrict__ slabs, int nslabs, int D,
+                                                      const cetkmc_event* __restrict__ dom_events, const StepState* __restrict__ ss)
 {
+    __shared__ int cnt[TOUCH_MAX_SLABS], base[TOUCH_MAX_SLABS];
     if (ss->status) return;
-    const cetkmc_event ev = dom_events[blockIdx.x];
-    if (ev.type < 0) return;
-    apply_touch(P, slabs, nslabs, ktab_g, ev, threadIdx.x, 0);
+    const int tid = threadIdx.x;
+    if (tid < nslabs) cnt[tid] = 0;
+    __syncthreads();
+    const int d = blockIdx.x * 8 + (tid >> 5), l = tid & 31;
+    int my_slab = -1, my_rank = 0;
+    unsigned my_entry = 0;
+    if (d < D && l != 15 && l != 31) {
+        const cetkmc_event ev = dom_events[d];
+        const bool second = l >= 16;
+        if (ev.type >= 0 && (!second || ev.type == EV_DIFF)) {
+            int ai = second ? ev.target[0] : ev.pos[0], aj = second ? ev.target[1] : ev.pos[1], ak = second ? ev.target[2] : ev.pos[2];
+            const int m = l & 15;
+            if (m < 14) { ai += nbi_rt(m); aj += nbj_rt(m); ak += nbk_rt(m); }
+            for (int s = 0; s < nslabs; ++s) {
+                const SlabView& S = slabs[s];
+                const int lp = ai - S.gi0;
+                if (ai < 0 || ai >= S.L || aj < 0 || aj >= S.L || ak < 0 || ak >= S.L || lp < 0 || lp >= S.nloc) continue;
+                const int li = lp + 2;
+                bool hit;
+                const unsigned code = ifc_encode(S, li, aj, ak, &hit);
+                const int64_t t = S.tidx(li, aj, ak);
+                bool listed = S.ifc_in[t] != 0;
+                if (hit && !listed) {
+                    unsigned* w = reinterpret_cast<unsigned*>(S.ifc_in + (t & ~(int64_t)3));
+                    const unsigned bit = 1u << (8 * (int)(t & 3));
+                    if (!(atomicOr(w, bit) & bit)) {
+                        my_slab = s;
+                        my_rank = atomicAdd(&cnt[s], 1);
+                        my_entry = ((unsigned)lp << 20) | ((unsigned)aj << 10) | (unsigned)ak;
+                    }
+                    listed = true;
+                }
+                if (listed) S.ifc_code[t] = code;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < nslabs && cnt[tid] > 0) base[tid] = atomicAdd(slabs[tid].ifc_n, cnt[tid]);
+    __syncthreads();
+    if (my_slab >= 0) slabs[my_slab].ifc_list[base[my_slab] + my_rank] = my_entry;
 }
 
 __global__ void k_super_commit(StepState* ss, unsigned long long* counters, double* log_total, int64_t* log_exec)
