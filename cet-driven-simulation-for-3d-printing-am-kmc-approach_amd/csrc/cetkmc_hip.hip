@@ -420,11 +420,14 @@ int download_impl(Handle* h, int i_begin, int i_end, I* state, double* theta, do
 }
 
 // ---- per-step launches (all asynchronous on h->stream) -----------------------------------
-int launch_interface(Handle* h, bool batch, hipStream_t st)
+int launch_interface(Handle* h, bool batch, hipStream_t st, bool long_list = false)
 {
     const StepState* ss = batch ? h->d_ss : nullptr;
     for (size_t s = 0; s < h->slabs.size(); ++s)
-        hipLaunchKernelGGL(k_interface, dim3(h->ifc_blocks * (256 / h->ifc_block)), dim3(h->ifc_block), 0, st, h->kp,
+        if (long_list)
+            hipLaunchKernelGGL(k_interface_part, dim3(2048), dim3(256), 0, st, h->kp, view_of(h, (int)s), h->d_ktab, ss);
+        else
+            hipLaunchKernelGGL(k_interface, dim3(h->ifc_blocks * (256 / h->ifc_block)), dim3(h->ifc_block), 0, st, h->kp,
                            view_of(h, (int)s), h->d_ktab, ss);
     HIPCHK(hipGetLastError());
     return 0;
@@ -470,7 +473,7 @@ int launch_sweep(Handle* h, bool batch, hipEvent_t ev_a = nullptr, hipEvent_t ev
     const size_t shmem0 = (size_t)((5 * TR * h->pitchS + 15) & ~15) + 225 * sizeof(double);
     const StepState* ss = batch ? h->d_ss : nullptr;
     const int njt = (h->L + SWEEP_TJ - 1) / SWEEP_TJ;
-    if (h->sweep_variant == 1 && !skip_ifc) CHK(launch_interface(h, batch, h->stream));
+    if (h->sweep_variant == 1 && !skip_ifc) CHK(launch_interface(h, batch, h->stream, write_vox));
     if (ev_a) HIPCHK(hipEventRecord(ev_a, h->stream));
     for (size_t s = 0; s < h->slabs.size(); ++s) {
         SlabView v = view_of(h, (int)s);
@@ -1061,7 +1064,6 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
     if (h->comm && h->nranks > 1) return fail("cetkmc_run_supersteps: single process only");
     if (h->sweep_variant != 1) return fail("cetkmc_run_supersteps needs sweep_variant 1");
     if (a->box < 8 || a->box > 16 || (a->box & 1) || h->L % a->box) return fail("box must be even, 8..16, and divide L");
-    if ((int)h->slabs.size() > TOUCH_MAX_SLABS) return fail("cetkmc_run_supersteps: too many slabs");
     int64_t n_therm = 0;
     if (a->thermal_mode) for (int64_t s = 0; s < n; ++s) if ((a->step0 + s) % 20 == 0) ++n_therm;
     if (a->thermal_mode == 2 && (n_therm > a->n_q || (n_therm > 0 && !a->q_planes)))
@@ -1121,6 +1123,11 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
                            (int)h->slabs.size(), h->L, D, C, h->d_ss, (const DomPick*)d_picks, (const double*)h->d_ktab, d_dom, d_cnt, d_log);
         hipLaunchKernelGGL(k_domain_touch, dim3((D + 7) / 8), dim3(256), 0, h->stream, (const SlabView*)h->d_views[h->cur],
                            (int)h->slabs.size(), D, (const cetkmc_event*)d_dom, (const StepState*)h->d_ss);
+        for (size_t sl = 0; sl < h->slabs.size(); ++sl) {
+            SlabView v = view_of(h, (int)sl);
+            HIPCHK(hipMemsetAsync(v.ifc_n, 0, sizeof(int), h->stream));
+            hipLaunchKernelGGL(k_ifc_relist, dim3((v.nloc * h->L + RELIST_ROWS - 1) / RELIST_ROWS), dim3(256), 0, h->stream, v, (const StepState*)nullptr);
+        }
         hipLaunchKernelGGL(k_super_commit, dim3(1), dim3(1), 0, h->stream, h->d_ss, d_cnt, h->d_log_total, h->d_log_nev);
         h->swept = false;
     }

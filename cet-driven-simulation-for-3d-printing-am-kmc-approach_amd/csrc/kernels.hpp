@@ -262,6 +262,8 @@ __device__ __forceinline__ void sweep_row(const StreamArgs& A, const double* kta
             acc.x += Aw + own.y; acc.y += own.x + Cw;
             // ---- per-voxel part (two voxels per trip: keeps the register footprint small) ----
             double p0 = 0.0, p1 = 0.0, p2 = 0.0;             // even voxel of the current pair
+            double pw = 0.0;                                 // WV: value / count of the even voxel
+            unsigned pc = 0;
 #pragma unroll 2
             for (int h = 0; h < 4; ++h) {
                 const int sh = 16 * (h & 1);
@@ -269,6 +271,7 @@ __device__ __forceinline__ void sweep_row(const StreamArgs& A, const double* kta
                 const unsigned oc = ((h < 2 ? own.x : own.y) >> sh) & 0xFFFFu;
                 const bool empty = (oc & 0x10u) != 0;
                 double ev = 0.0, dv = 0.0, depv = 0.0;
+                unsigned wc = 0;
                 if (empty) {
                     const double Traw = (h < 2) ? (h == 0 ? Ta.x : Ta.y) : (h == 2 ? Tb.x : Tb.y);
                     const double Tc = pymax(Traw, 1.0);
@@ -278,21 +281,30 @@ __device__ __forceinline__ void sweep_row(const StreamArgs& A, const double* kta
                     }
                     if (f & 0x0F00u) {                       // has W/Re/C neighbours: interface voxel
                         ev = A.ifc_val[trow + h];
-                        cemp += A.ifc_cnt[trow + h];
+                        wc = A.ifc_cnt[trow + h];
+                        cemp += wc;
                     } else {
                         const double dT = A.T_melt - Tc;
                         if (dT > A.delta_T_c) {
                             const int n_nb = f & 15, n_imp = (f >> 12) & 15;
                             const double rate = nuc_rate_s(A.I0, ktab[n_nb * 15 + n_imp], dT, A.kT * Tc);
-                            if (rate > A.rate_threshold) { ev = rate; ++cemp; }   // <= I0: always finite
+                            if (rate > A.rate_threshold) { ev = rate; ++cemp; wc = 1; }   // <= I0: always finite
                         }
                     }
-                    if (WV && !(f & 0x0F00u) && k0 + h < L) { A.ifc_val[trow + h] = ev; A.ifc_cnt[trow + h] = (uint8_t)(ev != 0.0); }
                 } else if ((oc & 0x100u) && (f & 0x00F0u)) { // atom with empty neighbours
                     dv = A.ifc_val[trow + h];
-                    cdiff += A.ifc_cnt[trow + h];
-                } else if (WV && k0 + h < L) {
-                    A.ifc_val[trow + h] = 0.0; A.ifc_cnt[trow + h] = 0;
+                    wc = A.ifc_cnt[trow + h];
+                    cdiff += wc;
+                }
+                if (WV) {
+                    // every voxel's EMPTY-or-DIFF sum goes back (interface voxels: the value just loaded), one
+                    // 16-byte + one 2-byte store per voxel pair
+                    const double wv = empty ? ev : dv;
+                    if (!(h & 1)) { pw = wv; pc = wc; }
+                    else if (k0 + h - 1 < L) {
+                        *reinterpret_cast<double2*>(A.ifc_val + trow + h - 1) = make_double2(pw, wv);
+                        *reinterpret_cast<uint16_t*>(A.ifc_cnt + trow + h - 1) = (uint16_t)(pc | (wc << 8));
+                    }
                 }
                 if (!(h & 1)) { p0 = depv; p1 = dv; p2 = ev; }
                 else if (h == 1) { s0 = p0 + depv; s1 = p1 + dv; s2 = p2 + ev; }
@@ -701,6 +713,81 @@ __device__ __forceinline__ void ifc_touch(const KParams& P, const SlabView& S, c
         S.ifc_cnt[t] = (uint8_t)cnt;
     }
 }
+// EMPTY-category sum of a listed empty voxel (nuc + attachments) / DIFF-category sum of a listed atom, from its
+// packed neighbourhood word alone
+__device__ __forceinline__ void ifc_eval_empty(const KParams& P, const SlabView& S, const double* ktab, int lp, int j, int k,
+                                               int64_t t, unsigned code, double Tc, double& sum, int& cnt)
+{
+    const int li = lp + 2;
+    // in-lattice neighbour count from the coordinates (kmc_event_rates.py:32,37)
+    const int i = S.gi0 + lp, L = S.L;
+    int n_nb = 0, n_imp = 0;
+    unsigned mask = 0;
+#pragma unroll
+    for (int m = 0; m < 14; ++m) {
+        const int ni = i + nbi_rt(m), nj = j + nbj_rt(m), nk = k + nbk_rt(m);
+        n_nb += (ni >= 0 && ni < L && nj >= 0 && nj < L && nk >= 0 && nk < L);
+        const unsigned c = (code >> (2 * m)) & 3u;
+        n_imp += (c >= 2u);
+        if (c) mask |= 1u << m;
+    }
+    const double dT = P.T_melt - Tc;
+    if (dT > P.delta_T_c) {
+        const double rate = nuc_rate(P, ktab[n_nb * 15 + n_imp], dT, P.kT * Tc);
+        if (rate > P.rate_threshold && finite_d(rate)) { sum = rate; cnt = 1; }
+    }
+    if (mask) {
+        const AttCtx c = att_ctx(P, S, li, j, k, Tc);
+        while (mask) {                                   // batches of 4 attachment sources
+            int ms[4];
+            double b[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ms[u] = mask ? __builtin_ctz(mask) : -1;
+                mask &= mask - 1;
+                const int m = ms[u] < 0 ? 0 : ms[u];
+                const double* p = S.ovec + 3 * (ms[u] < 0 ? t : S.tidx(li + nbi_rt(m), j + nbj_rt(m), k + nbk_rt(m)));
+                b[u][0] = p[0]; b[u][1] = p[1]; b[u][2] = p[2];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (ms[u] >= 0) {
+                    const int sn = (int)((code >> (2 * ms[u])) & 3u);
+                    const double rate = att_item(P, c, b[u][0], b[u][1], b[u][2], sn);
+                    if (rate > P.rate_threshold && finite_d(rate)) { sum = sum + rate; ++cnt; }
+                }
+            }
+        }
+    }
+}
+__device__ __forceinline__ void ifc_eval_atom(const KParams& P, const SlabView& S, int lp, int j, int k, int64_t t,
+                                              unsigned code, int st, double Tc, double& sum, int& cnt)
+{
+    const int li = lp + 2;
+    int n_bonds = 0;
+    unsigned mask = 0;
+#pragma unroll
+    for (int m = 0; m < 14; ++m) {
+        const unsigned c = (code >> (2 * m)) & 3u;
+        n_bonds += (c == 2u);
+        if (c == 1u) mask |= 1u << m;
+    }
+    if (mask) {
+        const DiffCtx c = diff_ctx(P, S, li, j, k, st, n_bonds, Tc);
+        double Tn[14];
+#pragma unroll
+        for (int m = 0; m < 14; ++m)                       // all neighbour temperatures in one round trip
+            Tn[m] = S.T[(mask >> m) & 1u ? S.tidx(li + nbi_rt(m), j + nbj_rt(m), k + nbk_rt(m)) : t];
+#pragma unroll
+        for (int m = 0; m < 14; ++m) {
+            if ((mask >> m) & 1u) {
+                const double rate = diff_item(P, c, Tn[m]);
+                if (rate > P.rate_threshold && finite_d(rate)) { sum = sum + rate; ++cnt; }
+            }
+        }
+    }
+}
+
 // every step: EMPTY/DIFF category sum + count of every listed voxel, one voxel per lane.
 // Latency-bound gather kernel: all loads of a phase are issued together (own fields + 14
 // neighbour states, then 7 neighbours' vectors / temperatures at a time from clamped-safe
@@ -716,80 +803,67 @@ __global__ __launch_bounds__(256) void k_interface(KParams P, SlabView S, const 
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
         const unsigned v = S.ifc_list[q];
         const int lp = v >> 20, j = (v >> 10) & 1023, k = v & 1023;
-        const int li = lp + 2;
-        const int64_t t = S.tidx(li, j, k);
+        const int64_t t = S.tidx(lp + 2, j, k);
         const unsigned code = S.ifc_code[t];
         const int st = (code >> 30) ? 4 : (int)((code >> 28) & 3u);     // 4: no events
         const double Tc = pymax(S.T[t], 1.0);
         double sum = 0.0;
         int cnt = 0;
-        if (st == 0) {
-            // in-lattice neighbour count from the coordinates (kmc_event_rates.py:32,37)
-            const int i = S.gi0 + lp, L = S.L;
-            int n_nb = 0, n_imp = 0;
-            unsigned mask = 0;
-#pragma unroll
-            for (int m = 0; m < 14; ++m) {
-                const int ni = i + nbi_rt(m), nj = j + nbj_rt(m), nk = k + nbk_rt(m);
-                n_nb += (ni >= 0 && ni < L && nj >= 0 && nj < L && nk >= 0 && nk < L);
-                const unsigned c = (code >> (2 * m)) & 3u;
-                n_imp += (c >= 2u);
-                if (c) mask |= 1u << m;
-            }
-            const double dT = P.T_melt - Tc;
-            if (dT > P.delta_T_c) {
-                const double rate = nuc_rate(P, ktab[n_nb * 15 + n_imp], dT, P.kT * Tc);
-                if (rate > P.rate_threshold && finite_d(rate)) { sum = rate; cnt = 1; }
-            }
-            if (mask) {
-                const AttCtx c = att_ctx(P, S, li, j, k, Tc);
-                while (mask) {                                   // batches of 4 attachment sources
-                    int ms[4];
-                    double b[4][3];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        ms[u] = mask ? __builtin_ctz(mask) : -1;
-                        mask &= mask - 1;
-                        const int m = ms[u] < 0 ? 0 : ms[u];
-                        const double* p = S.ovec + 3 * (ms[u] < 0 ? t : S.tidx(li + nbi_rt(m), j + nbj_rt(m), k + nbk_rt(m)));
-                        b[u][0] = p[0]; b[u][1] = p[1]; b[u][2] = p[2];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (ms[u] >= 0) {
-                            const int sn = (int)((code >> (2 * ms[u])) & 3u);
-                            const double rate = att_item(P, c, b[u][0], b[u][1], b[u][2], sn);
-                            if (rate > P.rate_threshold && finite_d(rate)) { sum = sum + rate; ++cnt; }
-                        }
-                    }
-                }
-            }
-        } else if (st != 4) {
-            int n_bonds = 0;
-            unsigned mask = 0;
-#pragma unroll
-            for (int m = 0; m < 14; ++m) {
-                const unsigned c = (code >> (2 * m)) & 3u;
-                n_bonds += (c == 2u);
-                if (c == 1u) mask |= 1u << m;
-            }
-            if (mask) {
-                const DiffCtx c = diff_ctx(P, S, li, j, k, st, n_bonds, Tc);
-                double Tn[14];
-#pragma unroll
-                for (int m = 0; m < 14; ++m)                       // all neighbour temperatures in one round trip
-                    Tn[m] = S.T[(mask >> m) & 1u ? S.tidx(li + nbi_rt(m), j + nbj_rt(m), k + nbk_rt(m)) : t];
-#pragma unroll
-                for (int m = 0; m < 14; ++m) {
-                    if ((mask >> m) & 1u) {
-                        const double rate = diff_item(P, c, Tn[m]);
-                        if (rate > P.rate_threshold && finite_d(rate)) { sum = sum + rate; ++cnt; }
-                    }
-                }
-            }
-        }
+        if (st == 0) ifc_eval_empty(P, S, ktab, lp, j, k, t, code, Tc, sum, cnt);
+        else if (st != 4) ifc_eval_atom(P, S, lp, j, k, t, code, st, Tc, sum, cnt);
         S.ifc_val[t] = sum;
         S.ifc_cnt[t] = (uint8_t)cnt;
+    }
+}
+
+// Same results for long lists (Mode B, where most of the lattice becomes interface): a block takes tiles of
+// 1024 entries, sorts them by kind (empty / atom) into two LDS queues and evaluates each queue with full
+// waves, so that a wave runs only one of the two (expensive, differently shaped) rate loops.
+constexpr int IFC_TILE = 1024;
+__global__ __launch_bounds__(256) void k_interface_part(KParams P, SlabView S, const double* __restrict__ ktab_g,
+                                                        const StepState* __restrict__ ss)
+{
+    if (ss && ss->status) return;
+    __shared__ double ktab[225];
+    __shared__ unsigned qe[IFC_TILE], qa[IFC_TILE];
+    __shared__ int ne, na;
+    const int tid = threadIdx.x;
+    for (int t = tid; t < 225; t += 256) ktab[t] = ktab_g[t];
+    const int n = *S.ifc_n;
+    for (int tile = blockIdx.x * IFC_TILE; tile < n; tile += gridDim.x * IFC_TILE) {
+        __syncthreads();
+        if (tid == 0) { ne = 0; na = 0; }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < IFC_TILE / 256; ++u) {
+            const int q = tile + u * 256 + tid;
+            if (q < n) {
+                const unsigned v = S.ifc_list[q];
+                const unsigned code = S.ifc_code[S.tidx((int)(v >> 20) + 2, (v >> 10) & 1023, v & 1023)];
+                if (code >> 30) {                                       // no events: result is zero
+                    const int64_t t = S.tidx((int)(v >> 20) + 2, (v >> 10) & 1023, v & 1023);
+                    S.ifc_val[t] = 0.0; S.ifc_cnt[t] = 0;
+                } else if (((code >> 28) & 3u) == 0) qe[atomicAdd(&ne, 1)] = v;
+                else qa[atomicAdd(&na, 1)] = v;
+            }
+        }
+        __syncthreads();
+        const int ne_pad = (ne + 63) & ~63, work = ne_pad + na;
+        for (int w = tid; w < work; w += 256) {
+            const bool is_e = w < ne_pad;
+            if (is_e && w >= ne) continue;
+            const unsigned v = is_e ? qe[w] : qa[w - ne_pad];
+            const int lp = v >> 20, j = (v >> 10) & 1023, k = v & 1023;
+            const int64_t t = S.tidx(lp + 2, j, k);
+            const unsigned code = S.ifc_code[t];
+            const double Tc = pymax(S.T[t], 1.0);
+            double sum = 0.0;
+            int cnt = 0;
+            if (is_e) ifc_eval_empty(P, S, ktab, lp, j, k, t, code, Tc, sum, cnt);
+            else ifc_eval_atom(P, S, lp, j, k, t, code, (int)((code >> 28) & 3u), Tc, sum, cnt);
+            S.ifc_val[t] = sum;
+            S.ifc_cnt[t] = (uint8_t)cnt;
+        }
     }
 }
 

@@ -163,55 +163,73 @@ __global__ __launch_bounds__(64) void k_domain_slot_apply(KParams P, const SlabV
     if (ev.type == EV_NUC) atomicAdd(&counters[1], 1ull);
 }
 
-// Interface-list upkeep for the touched voxels, after ALL lattice writes of the super-step.  8 boxes per
-// 256-thread block, 32 lanes per event (0..14 neighbourhood of the site, 16..30 of a diffusion target).  New
-// list entries are claimed by test-and-set on ifc_in and appended with ONE global atomic per block and slab.
-constexpr int TOUCH_MAX_SLABS = 64;
+// Interface upkeep for the touched voxels, after ALL lattice writes of the super-step.  8 boxes per 256-thread
+// block, 32 lanes per event (0..14 neighbourhood of the site, 16..30 of a diffusion target).  Only the
+// membership flag and the packed neighbourhood word are updated here; the list itself is rebuilt in address
+// order by k_ifc_relist (Mode B lists are long, and k_interface is bound by the locality of its gathers).
 __global__ __launch_bounds__(256) void k_domain_touch(const SlabView* __restrict__ slabs, int nslabs, int D,
                                                       const cetkmc_event* __restrict__ dom_events, const StepState* __restrict__ ss)
 {
-    __shared__ int cnt[TOUCH_MAX_SLABS], base[TOUCH_MAX_SLABS];
     if (ss->status) return;
     const int tid = threadIdx.x;
-    if (tid < nslabs) cnt[tid] = 0;
-    __syncthreads();
     const int d = blockIdx.x * 8 + (tid >> 5), l = tid & 31;
-    int my_slab = -1, my_rank = 0;
-    unsigned my_entry = 0;
-    if (d < D && l != 15 && l != 31) {
-        const cetkmc_event ev = dom_events[d];
-        const bool second = l >= 16;
-        if (ev.type >= 0 && (!second || ev.type == EV_DIFF)) {
-            int ai = second ? ev.target[0] : ev.pos[0], aj = second ? ev.target[1] : ev.pos[1], ak = second ? ev.target[2] : ev.pos[2];
-            const int m = l & 15;
-            if (m < 14) { ai += nbi_rt(m); aj += nbj_rt(m); ak += nbk_rt(m); }
-            for (int s = 0; s < nslabs; ++s) {
-                const SlabView& S = slabs[s];
-                const int lp = ai - S.gi0;
-                if (ai < 0 || ai >= S.L || aj < 0 || aj >= S.L || ak < 0 || ak >= S.L || lp < 0 || lp >= S.nloc) continue;
-                const int li = lp + 2;
-                bool hit;
-                const unsigned code = ifc_encode(S, li, aj, ak, &hit);
-                const int64_t t = S.tidx(li, aj, ak);
-                bool listed = S.ifc_in[t] != 0;
-                if (hit && !listed) {
-                    unsigned* w = reinterpret_cast<unsigned*>(S.ifc_in + (t & ~(int64_t)3));
-                    const unsigned bit = 1u << (8 * (int)(t & 3));
-                    if (!(atomicOr(w, bit) & bit)) {
-                        my_slab = s;
-                        my_rank = atomicAdd(&cnt[s], 1);
-                        my_entry = ((unsigned)lp << 20) | ((unsigned)aj << 10) | (unsigned)ak;
-                    }
-                    listed = true;
-                }
-                if (listed) S.ifc_code[t] = code;
-            }
-        }
+    if (d >= D || l == 15 || l == 31) return;
+    const cetkmc_event ev = dom_events[d];
+    const bool second = l >= 16;
+    if (ev.type < 0 || (second && ev.type != EV_DIFF)) return;
+    int ai = second ? ev.target[0] : ev.pos[0], aj = second ? ev.target[1] : ev.pos[1], ak = second ? ev.target[2] : ev.pos[2];
+    const int m = l & 15;
+    if (m < 14) { ai += nbi_rt(m); aj += nbj_rt(m); ak += nbk_rt(m); }
+    for (int s = 0; s < nslabs; ++s) {
+        const SlabView& S = slabs[s];
+        const int lp = ai - S.gi0;
+        if (ai < 0 || ai >= S.L || aj < 0 || aj >= S.L || ak < 0 || ak >= S.L || lp < 0 || lp >= S.nloc) continue;
+        bool hit;
+        const unsigned code = ifc_encode(S, lp + 2, aj, ak, &hit);
+        const int64_t t = S.tidx(lp + 2, aj, ak);
+        if (hit) S.ifc_in[t] = 1;
+        if (hit || S.ifc_in[t]) S.ifc_code[t] = code;
+    }
+}
+
+// Rebuild a slab's interface list from the membership flags, in address order inside each block's 32 rows
+// (one global atomic per block).  *S.ifc_n must be zero at launch.
+constexpr int RELIST_ROWS = 32;
+__global__ __launch_bounds__(256) void k_ifc_relist(SlabView S, const StepState* __restrict__ ss)
+{
+    __shared__ int wsum[4], wbase[4];
+    __shared__ int base;
+    if (ss && ss->status) return;
+    const int L = S.L, nrows = S.nloc * L;
+    const int r0 = blockIdx.x * RELIST_ROWS, r1 = min(r0 + RELIST_ROWS, nrows);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int cnt = 0;
+    for (int r = r0 + w; r < r1; r += 4) {
+        const int lp = r / L, j = r - lp * L;
+        const uint8_t* row = S.ifc_in + S.tidx(lp + 2, j, 0);
+        for (int k = lane; k < L; k += 64) cnt += row[k] != 0;
+    }
+    cnt = wave_sum_i(cnt);
+    if (lane == 0) wsum[w] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        int tot = 0;
+        for (int q = 0; q < 4; ++q) { wbase[q] = tot; tot += wsum[q]; }
+        base = tot ? atomicAdd(S.ifc_n, tot) : 0;
     }
     __syncthreads();
-    if (tid < nslabs && cnt[tid] > 0) base[tid] = atomicAdd(slabs[tid].ifc_n, cnt[tid]);
-    __syncthreads();
-    if (my_slab >= 0) slabs[my_slab].ifc_list[base[my_slab] + my_rank] = my_entry;
+    int off = base + wbase[w];
+    for (int r = r0 + w; r < r1; r += 4) {
+        const int lp = r / L, j = r - lp * L;
+        const uint8_t* row = S.ifc_in + S.tidx(lp + 2, j, 0);
+        for (int k0 = 0; k0 < L; k0 += 64) {
+            const int k = k0 + lane;
+            const bool f = k < L && row[k] != 0;
+            const unsigned long long mask = __ballot(f);
+            if (f) S.ifc_list[off + __popcll(mask & ((1ull << lane) - 1ull))] = ((unsigned)lp << 20) | ((unsigned)j << 10) | (unsigned)k;
+            off += __popcll(mask);
+        }
+    }
 }
 
 __global__ void k_super_commit(StepState* ss, unsigned long long* counters, double* log_total, int64_t* log_exec)
