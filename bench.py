@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--L", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-incremental", action="store_true", help="skip the extra exact-incremental-mode run")
+    ap.add_argument("--no-mode-b", action="store_true", help="skip the extra Mode B (super-step) run")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-process code path (gloo rendezvous + RCCL communicator) even with one rank")
@@ -200,6 +201,23 @@ def main():
                            "rows the previous event made stale are re-evaluated; bit-identical to full sweeps "
                            "(tests/test_gpu_parity.py::test_incremental_mode_bit_identical); not part of `value`"}
 
+    # ---- Mode B (super-steps over 8^3 boxes; not the reference's trajectory, own CPU comparator): executed events/s
+    mode_b = None
+    if N == 1 and not a.no_mode_b and L % 8 == 0:
+        sb, nb_steps = step + 2 * a.steps, 40
+        qb = synthetic.laser_planes(L, sb, nb_steps)
+        eng.sync()
+        t2 = time.perf_counter()
+        rb = eng.run_supersteps(sb, nb_steps, 8, DEFECT_FRACTION, seed=SEED, thermal_mode=2, q_planes=qb)
+        eng.sync()
+        dtb = time.perf_counter() - t2
+        if rb["done"] == nb_steps:
+            mode_b = {"executed_events_per_s": float(rb["n_exec"].sum()) / dtb, "ms_per_superstep": 1e3 * dtb / nb_steps,
+                      "events_per_superstep": float(rb["n_exec"].mean()), "boxes": rb["domains"], "supersteps": nb_steps,
+                      "note": "cetkmc_run_supersteps box=8 on the lattice left by the runs above: one full rate sweep per "
+                              "super-step, every box executes <= 1 event from its active octant; bit-identical to "
+                              "oracle orc_run_supersteps (tests/test_gpu_mode_b.py); not part of `value`"}
+
     cand = float(np.sum(r["n_events"].astype(np.float64)))     # identical on every rank (global counts)
     steps_per_s = a.steps / dt
     sweep_ms = r["sweep_ms_total"] / max(r["sweep_launches"], 1)
@@ -245,6 +263,8 @@ def main():
         }
     if inc is not None:
         out["incremental_exact"] = inc
+    if mode_b is not None:
+        out["mode_b"] = mode_b
     if rank == 0:
         print(json.dumps(out))
     eng.close()

@@ -21,6 +21,13 @@ src, dst = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
 
+def kname(raw):
+    """cetkmc::k_sweep_stream<8, true>(...) -> k_sweep_stream_wv (write-back instantiation, Mode B only)"""
+    head = raw.split("(")[0].replace("cetkmc::", "").replace("void ", "")
+    base = head.split("<")[0]
+    return base + ("_wv" if "<" in head and "true" in head.split("<", 1)[1] else "")
+
+
 def one(pattern):
     g = glob.glob(os.path.join(src, pattern))
     return g[0] if g else None
@@ -31,7 +38,7 @@ summary = {"tag": tag, "kernels": {}}
 if stats:
     shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
     for r in csv.DictReader(open(stats)):
-        name = r["Name"].split("(")[0].replace("cetkmc::", "").replace("void ", "").split("<")[0]
+        name = kname(r["Name"])
         summary["kernels"][name] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
                                     "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3,
                                     "pct": float(r["Percentage"])}
@@ -41,7 +48,7 @@ for which in ("fetch", "write"):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        name = r["Kernel_Name"].split("(")[0].replace("cetkmc::", "").replace("void ", "").split("<")[0]
+        name = kname(r["Kernel_Name"])
         agg[name].append(float(r["Counter_Value"]))
     for name, v in agg.items():
         summary["kernels"].setdefault(name, {})[f"{which}_size_kb_median"] = statistics.median(v)
@@ -50,6 +57,14 @@ for name, k in summary["kernels"].items():
         wide = name in ("k_sweep_stream", "k_thermal", "k_thermal_march")
         k["hbm_bytes_per_launch"] = (2.0 if wide else 1.0) * k["fetch_size_kb_median"] * 1024 + k["write_size_kb_median"] * 1024
         k["fetch_x2_applied"] = wide
+modes = one(f"{tag}_stats_modes/*/*kernel_stats.csv")
+if modes:       # second pass: the incremental and Mode B loops (their kernels only)
+    shutil.copy(modes, os.path.join(dst, f"{tag}_kernel_stats_modes.csv"))
+    summary["kernels_modes"] = {}
+    for r in csv.DictReader(open(modes)):
+        summary["kernels_modes"][kname(r["Name"])] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
+                                                      "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3,
+                                                      "pct": float(r["Percentage"])}
 for f in (f"{tag}_bench.json", f"{tag}_bench_under_rocprof.json"):
     p = os.path.join(src, f)
     if os.path.exists(p) and os.path.getsize(p):
