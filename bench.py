@@ -47,32 +47,39 @@ def streams(n, seed):
 
 
 def cpu_baseline(L, fields, n_gpu_events, budget_s=15.0):
-    """Oracle (C restatement, 1 core) on the first steps of the same workload; also checks the
-    GPU's chosen events for those steps (full-size parity)."""
+    """Oracle (C restatement) on the first steps of the same workload: first as the scalar port (1 core, half the
+    budget), then with its row / thermal loops on the box's CPU share (OpenMP); also checks the GPU's chosen
+    events for those steps (full-size parity)."""
     from cetkmc import synthetic
     from oracle import oracle
     state, theta, phi, T, defects = fields
     lat = oracle.Lattice(state, theta, phi, T, defects, impurity_c=IMPURITY_C)
-    done, t_used, ev_all, nev_all = 0, 0.0, [], []
+    done, ev_all, nev_all = 0, [], []
     n_max = len(n_gpu_events)
-    while done < n_max:
-        n = 1
-        u_pick, u_def, u_np = streams(n_max, SEED)
-        q = synthetic.laser_planes(L, done, n)
-        t0 = time.perf_counter()
-        # rng_mode 1 consumes only orientation draws; replay the cursor from the GPU log
-        res = lat.run_steps(done, n, DEFECT_FRACTION, u_pick[done:done + n], u_def[done:done + n],
-                            u_np[cpu_baseline.np_pos:], rng_mode=1, seed=SEED, thermal_mode=2, q_planes=q)
-        t_used += time.perf_counter() - t0
-        cpu_baseline.np_pos += res["np_used"]
-        ev_all.append(res["events"])
-        nev_all.append(res["n_events"])
-        done += res["done"]
-        if res["done"] < n or t_used > budget_s:
-            break
+    n_threads = max(1, min(16, os.cpu_count() or 1))          # a 1-GPU box's CPU share
+    legs = {"single": [1, 0, 0.0], "multi": [n_threads, 0, 0.0]}     # threads, steps, seconds
+    for leg in ("single", "multi"):
+        oracle.set_threads(legs[leg][0])
+        while done < n_max:
+            n = 1
+            u_pick, u_def, u_np = streams(n_max, SEED)
+            q = synthetic.laser_planes(L, done, n)
+            t0 = time.perf_counter()
+            # rng_mode 1 consumes only orientation draws; replay the cursor from the GPU log
+            res = lat.run_steps(done, n, DEFECT_FRACTION, u_pick[done:done + n], u_def[done:done + n],
+                                u_np[cpu_baseline.np_pos:], rng_mode=1, seed=SEED, thermal_mode=2, q_planes=q)
+            legs[leg][2] += time.perf_counter() - t0
+            legs[leg][1] += res["done"]
+            cpu_baseline.np_pos += res["np_used"]
+            ev_all.append(res["events"])
+            nev_all.append(res["n_events"])
+            done += res["done"]
+            if res["done"] < n or legs[leg][2] > budget_s / 2 or (leg == "single" and legs[leg][1] >= n_max // 2):
+                break
+    oracle.set_threads(1)
     ev = np.concatenate(ev_all)
     nev = np.concatenate(nev_all)
-    return dict(steps=done, seconds=t_used, events=ev, n_events=nev)
+    return dict(steps=done, events=ev, n_events=nev, legs=legs)
 
 
 cpu_baseline.np_pos = 0
@@ -148,7 +155,7 @@ def main():
     step = 0
     base = None
     if N == 1 and not a.no_cpu_baseline:
-        n_chk = 12
+        n_chk = 40
         r = run(0, n_chk, logs=True)
         run.np_pos += r["np_used"]
         step = r["done"]
@@ -253,13 +260,18 @@ def main():
                      "alg_bytes_per_voxel": B_ALG_SWEEP, "voxels_per_launch": n_own},
     }
     if base is not None:
-        cpu_cand = float(np.sum(base["n_events"].astype(np.float64)))
+        nev = base["n_events"].astype(np.float64)
+        (t1, s1, sec1), (tm, sm, secm) = base["legs"]["single"], base["legs"]["multi"]
+        leg = ("multi", tm, sm, secm, float(nev[s1:s1 + sm].sum())) if sm > 0 else ("single", t1, s1, sec1, float(nev[:s1].sum()))
         out["cpu_baseline"] = {
-            "value": cpu_cand / base["seconds"], "unit": "events/s", "cores": 1, "kind": "port",
-            "sample": f"first {base['steps']} steps of the same {L}^3 workload on the C oracle "
-                      f"({base['seconds']:.1f} s, incl. thermal updates)",
-            "steps_per_s": base["steps"] / base["seconds"], "host_cores_available": os.cpu_count(),
-            "parity_first_steps": base["parity"],
+            "value": leg[4] / leg[3], "unit": "events/s", "cores": leg[1], "kind": "port",
+            "sample": f"steps {s1}..{s1 + sm} of the same {L}^3 workload on the C oracle with its row/thermal loops on "
+                      f"{leg[1]} host threads ({leg[3]:.1f} s, incl. thermal updates)" if sm > 0 else
+                      f"first {s1} steps of the same {L}^3 workload on the C oracle, 1 thread ({sec1:.1f} s)",
+            "steps_per_s": leg[2] / leg[3],
+            "single_core": {"value": float(nev[:s1].sum()) / sec1 if s1 else None, "steps_per_s": s1 / sec1 if s1 else None,
+                            "cores": 1, "sample": f"first {s1} steps, scalar port ({sec1:.1f} s)"},
+            "host_cores_available": os.cpu_count(), "parity_first_steps": base["parity"],
         }
     if inc is not None:
         out["incremental_exact"] = inc

@@ -21,6 +21,9 @@
  * state/defects are passed as int8 (values are 0..4 / 0..1 in the reference).
  */
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -301,23 +304,40 @@ void orc_row_sums(const orc_params *P, int L, const int8_t *state, const double 
                   int i0, int i1, double *rowsum, int32_t *rowcnt)
 {
     const int Pk = next_pow2(L);
-    double *vs = (double *)malloc(sizeof(double) * (size_t)Pk);
-    slots_t S;
-    for (int i = i0; i < i1; ++i)
-        for (int c = 0; c < 3; ++c)
-            for (int j = 0; j < L; ++j) {
-                int32_t cnt = 0;
-                for (int k = 0; k < L; ++k) {
-                    voxel_slots(P, L, state, theta, phi, T, defects, i, j, k, c, &S);
-                    double s = 0.0;
-                    for (int m = 0; m < S.n; ++m) s += S.rate[m];
-                    vs[k] = s;
-                    cnt += S.n;
+    /* planes are independent: threads (orc_set_threads) only change who computes a row, not its value */
+#pragma omp parallel
+    {
+        double *vs = (double *)malloc(sizeof(double) * (size_t)Pk);
+        slots_t S;
+#pragma omp for schedule(dynamic, 1)
+        for (int i = i0; i < i1; ++i)
+            for (int c = 0; c < 3; ++c)
+                for (int j = 0; j < L; ++j) {
+                    int32_t cnt = 0;
+                    for (int k = 0; k < L; ++k) {
+                        voxel_slots(P, L, state, theta, phi, T, defects, i, j, k, c, &S);
+                        double s = 0.0;
+                        for (int m = 0; m < S.n; ++m) s += S.rate[m];
+                        vs[k] = s;
+                        cnt += S.n;
+                    }
+                    rowsum[((int64_t)i * 3 + c) * L + j] = tree_sum(vs, 0, Pk, L);
+                    rowcnt[((int64_t)i * 3 + c) * L + j] = cnt;
                 }
-                rowsum[((int64_t)i * 3 + c) * L + j] = tree_sum(vs, 0, Pk, L);
-                rowcnt[((int64_t)i * 3 + c) * L + j] = cnt;
-            }
-    free(vs);
+        free(vs);
+    }
+}
+
+/* worker threads of the row / thermal loops (1 = the scalar port); returns the count in effect */
+int orc_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
 }
 
 /* Block sums from row sums for planes [i0,i1): blocksum[i*3+c], blockcnt. */
@@ -474,6 +494,7 @@ void orc_thermal_cet(const orc_params *P, int L, const double *Tin, double dt, i
     double *Ts = (double *)malloc(sizeof(double) * (size_t)n);
     for (int64_t m = 0; m < n; ++m) Ts[m] = scrub_nan ? scrub(P, Tin[m]) : Tin[m];
     const double dta = dt * P->alpha;
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < L; ++i)
         for (int j = 0; j < L; ++j)
             for (int k = 0; k < L; ++k) {
@@ -494,6 +515,7 @@ void orc_thermal_laser(const orc_params *P, int L, const double *Tin, const int8
     double *Ts = (double *)malloc(sizeof(double) * (size_t)n);
     for (int64_t m = 0; m < n; ++m) Ts[m] = scrub_nan ? scrub(P, Tin[m]) : Tin[m];
     const double dtm = dt > 1e-12 ? dt : 1e-12;           /* max(dt, 1e-12) :99 */
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < L; ++i)
         for (int j = 0; j < L; ++j)
             for (int k = 0; k < L; ++k) {

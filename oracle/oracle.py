@@ -103,6 +103,8 @@ def lib():
         L.orc_total.restype = C.c_double
         L.orc_run_steps.restype = C.c_int64
         L.orc_run_supersteps.restype = C.c_int64
+        L.orc_set_threads.restype = C.c_int
+        L.orc_set_threads(int(os.environ.get("CET_ORACLE_THREADS", "1")))   # scalar port unless asked otherwise
         L.orc_counter_uniform.restype = C.c_double
         L.orc_counter_uniform.argtypes = [C.c_uint64] * 3
         _lib = L
@@ -296,6 +298,11 @@ def laser_source_plane(L, laser_pos, laser_power, beam_radius=50e-6, absorptivit
 
 
 KEY_PICK, KEY_THETA, KEY_PHI, KEY_DEFECT = 1 << 40, 2 << 40, 3 << 40, 4 << 40    # Mode B uniform keys
+
+
+def set_threads(n):
+    """Worker threads of the row-sum / thermal loops (results do not depend on it); returns the count in effect."""
+    return lib().orc_set_threads(int(n))
 
 
 def counter_uniform(seed, step, site):

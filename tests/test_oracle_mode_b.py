@@ -61,3 +61,19 @@ def test_windows_and_disjointness(oracle_mod, L, box):
         assert len(w) == len(set(w))
     assert r["n_exec"].sum() > n or box == L          # several events per sweep
     assert (lat.state != before).sum() > 0
+
+
+def test_oracle_threads_do_not_change_results(oracle_mod):
+    """The oracle's row-sum and thermal loops may run on several host threads (bench.py's all-core CPU
+    baseline); rows are independent, so every output is bit-identical to the scalar run."""
+    outs = []
+    for nt in (1, 4):
+        assert oracle_mod.set_threads(nt) == nt
+        lat = _lat(oracle_mod, 14, 21, 0.3)
+        rs = np.random.RandomState(3)
+        n = 25
+        r = lat.run_steps(0, n, 0.05, rs.random_sample(n), rs.random_sample(n), rs.random_sample(n * 200), rng_mode=0,
+                          thermal_mode=1)
+        outs.append((r["totals"].tobytes(), r["events"].tobytes(), lat.state.tobytes(), lat.T.tobytes()))
+    oracle_mod.set_threads(1)
+    assert outs[0] == outs[1]
