@@ -521,6 +521,28 @@ int launch_select(Handle* h, const BatchCfg& cfg, double r_direct, int info_only
     return 0;
 }
 
+// selection + application of one batched step: one fused launch in a single process, select / all-gather / apply
+// across ranks
+int launch_select_apply(Handle* h, const BatchCfg& cfg, int eval_touched, int* dirty)
+{
+    if (!h->comm) {
+        hipLaunchKernelGGL(k_select_apply, dim3(1), dim3(256), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
+                           (int)h->slabs.size(), h->L, h->PB, (const BlockEnt*)h->d_blocks, h->d_ss, cfg,
+                           (const double*)h->d_u_pick, (const double*)h->d_ktab, h->d_events_all + h->my_first,
+                           h->sweep_variant == 1 ? 1 : 0, (const double*)h->d_u_defect, (const double*)h->d_u_np,
+                           h->d_log_total, h->d_log_event, h->d_log_nev, eval_touched, dirty);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    CHK(launch_select(h, cfg, 0.0, 0));
+    hipLaunchKernelGGL(k_apply_batch, dim3(1), dim3(64), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
+                       (int)h->slabs.size(), h->L, (const cetkmc_event*)h->d_events_all, h->G, h->d_ss, cfg,
+                       (const double*)h->d_u_defect, (const double*)h->d_u_np, h->d_log_total, h->d_log_event,
+                       h->d_log_nev, (const double*)h->d_ktab, eval_touched, dirty);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int exchange_T_halo(Handle* h, int buf)
 {
     const size_t plane = (size_t)h->L * h->pitchT;   // doubles
@@ -991,11 +1013,7 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
         if (incr && s > 0 && !therm) {
             // exact incremental step: rates can only have changed in the rows recorded by the last apply
             CHK(launch_dirty_rows(h, a->profile ? h->prof[2 * s] : nullptr, a->profile ? h->prof[2 * s + 1] : nullptr));
-            CHK(launch_select(h, cfg, 0.0, 0));
-            hipLaunchKernelGGL(k_apply_batch, dim3(1), dim3(64), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
-                               (int)h->slabs.size(), h->L, (const cetkmc_event*)h->d_events_all, h->G, h->d_ss, cfg,
-                               (const double*)h->d_u_defect, (const double*)h->d_u_np, h->d_log_total, h->d_log_event,
-                               h->d_log_nev, (const double*)h->d_ktab, 1, h->d_dirty);
+            CHK(launch_select_apply(h, cfg, 1, h->d_dirty));
             h->swept = false;
             continue;
         }
@@ -1017,12 +1035,16 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
             CHK(launch_interface(h, true, h->stream2));
             HIPCHK(hipEventRecord(h->ev_ifc, h->stream2));
         }
-        CHK(launch_select(h, cfg, 0.0, 0));
-        if (spec) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ifc, 0));
-        hipLaunchKernelGGL(k_apply_batch, dim3(1), dim3(64), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
-                           (int)h->slabs.size(), h->L, (const cetkmc_event*)h->d_events_all, h->G, h->d_ss, cfg,
-                           (const double*)h->d_u_defect, (const double*)h->d_u_np, h->d_log_total, h->d_log_event,
-                           h->d_log_nev, (const double*)h->d_ktab, (spec || incr) ? 1 : 0, incr ? h->d_dirty : nullptr);
+        if (spec) {
+            CHK(launch_select(h, cfg, 0.0, 0));
+            HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ifc, 0));
+            hipLaunchKernelGGL(k_apply_batch, dim3(1), dim3(64), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
+                               (int)h->slabs.size(), h->L, (const cetkmc_event*)h->d_events_all, h->G, h->d_ss, cfg,
+                               (const double*)h->d_u_defect, (const double*)h->d_u_np, h->d_log_total, h->d_log_event,
+                               h->d_log_nev, (const double*)h->d_ktab, 1, incr ? h->d_dirty : nullptr);
+        } else {
+            CHK(launch_select_apply(h, cfg, incr ? 1 : 0, incr ? h->d_dirty : nullptr));
+        }
         ifc_fresh = spec;
         h->swept = false;
     }

@@ -491,10 +491,10 @@ __device__ __forceinline__ int heap_descend(const double* hs, const int* hf, int
 
 // k_select: single block.  (1) total + termination checks, (2) block descent, (3) row descent
 // in the owning slab, (4) voxel descent with the row's rates re-evaluated, (5) slot scan.
-__global__ __launch_bounds__(256) void k_select(KParams P, const SlabView* __restrict__ slabs, int nslabs, int L,
-                                                int PB, const BlockEnt* __restrict__ blocks, StepState* ss,
-                                                BatchCfg cfg, const double* __restrict__ u_pick, double r_direct,
-                                                const double* __restrict__ ktab_g, cetkmc_event* my_event, int info_only, int ifc_ready)
+__device__ __forceinline__ void select_body(const KParams& P, const SlabView* __restrict__ slabs, int nslabs, int L,
+                                            int PB, const BlockEnt* __restrict__ blocks, StepState* ss,
+                                            const BatchCfg& cfg, const double* __restrict__ u_pick, double r_direct,
+                                            const double* __restrict__ ktab_g, cetkmc_event* my_event, int info_only, int ifc_ready)
 {
     __shared__ double hs[2 * PMAX];
     __shared__ int hf[2 * PMAX];
@@ -623,6 +623,14 @@ __global__ __launch_bounds__(256) void k_select(KParams P, const SlabView* __res
         }
         *my_event = ev;
     }
+}
+
+__global__ __launch_bounds__(256) void k_select(KParams P, const SlabView* __restrict__ slabs, int nslabs, int L,
+                                                int PB, const BlockEnt* __restrict__ blocks, StepState* ss,
+                                                BatchCfg cfg, const double* __restrict__ u_pick, double r_direct,
+                                                const double* __restrict__ ktab_g, cetkmc_event* my_event, int info_only, int ifc_ready)
+{
+    select_body(P, slabs, nslabs, L, PB, blocks, ss, cfg, u_pick, r_direct, ktab_g, my_event, info_only, ifc_ready);
 }
 
 // ---- interface voxels --------------------------------------------------------------------
@@ -930,12 +938,12 @@ __device__ __forceinline__ int dep_species(const KParams& P, double u)
 
 // Batched apply: RNG bookkeeping of one step + lattice update + per-step logs (lane 0), then the
 // interface-list update for the touched voxels (whole wave).  Launched with ONE 64-thread block.
-__global__ __launch_bounds__(64) void k_apply_batch(KParams P, const SlabView* __restrict__ slabs, int nslabs, int L,
-                                                    const cetkmc_event* __restrict__ events_all, int G, StepState* ss,
-                                                    BatchCfg cfg, const double* __restrict__ u_defect,
-                                                    const double* __restrict__ u_np, double* log_total,
-                                                    cetkmc_event* log_event, int64_t* log_nev,
-                                                    const double* __restrict__ ktab_g, int eval_touched, int* dirty)
+__device__ __forceinline__ void apply_batch_body(const KParams& P, const SlabView* __restrict__ slabs, int nslabs, int L,
+                                                 const cetkmc_event* events_all, int G, StepState* ss,
+                                                 const BatchCfg& cfg, const double* __restrict__ u_defect,
+                                                 const double* __restrict__ u_np, double* log_total,
+                                                 cetkmc_event* log_event, int64_t* log_nev,
+                                                 const double* __restrict__ ktab_g, int eval_touched, int* dirty)
 {
     __shared__ cetkmc_event sh_ev;
     __shared__ int sh_ok;
@@ -996,6 +1004,33 @@ __global__ __launch_bounds__(64) void k_apply_batch(KParams P, const SlabView* _
         }
         dirty[0] = n;
     }
+}
+
+__global__ __launch_bounds__(64) void k_apply_batch(KParams P, const SlabView* __restrict__ slabs, int nslabs, int L,
+                                                    const cetkmc_event* __restrict__ events_all, int G, StepState* ss,
+                                                    BatchCfg cfg, const double* __restrict__ u_defect,
+                                                    const double* __restrict__ u_np, double* log_total,
+                                                    cetkmc_event* log_event, int64_t* log_nev,
+                                                    const double* __restrict__ ktab_g, int eval_touched, int* dirty)
+{
+    apply_batch_body(P, slabs, nslabs, L, events_all, G, ss, cfg, u_defect, u_np, log_total, log_event, log_nev, ktab_g,
+                     eval_touched, dirty);
+}
+// Single-process batched loop: selection and application in one launch (the event record never leaves the block's
+// view of memory; threads >= 64 only take part in the barriers of the apply part).
+__global__ __launch_bounds__(256) void k_select_apply(KParams P, const SlabView* __restrict__ slabs, int nslabs, int L,
+                                                      int PB, const BlockEnt* __restrict__ blocks, StepState* ss,
+                                                      BatchCfg cfg, const double* __restrict__ u_pick,
+                                                      const double* __restrict__ ktab_g, cetkmc_event* my_event, int ifc_ready,
+                                                      const double* __restrict__ u_defect, const double* __restrict__ u_np,
+                                                      double* log_total, cetkmc_event* log_event, int64_t* log_nev,
+                                                      int eval_touched, int* dirty)
+{
+    select_body(P, slabs, nslabs, L, PB, blocks, ss, cfg, u_pick, 0.0, ktab_g, my_event, 0, ifc_ready);
+    __threadfence_block();
+    __syncthreads();
+    apply_batch_body(P, slabs, nslabs, L, my_event, 1, ss, cfg, u_defect, u_np, log_total, log_event, log_nev, ktab_g,
+                     eval_touched, dirty);
 }
 
 // Direct apply (cetkmc_apply): everything decided by the host.  ONE 64-thread block.
