@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-incremental", action="store_true", help="skip the extra exact-incremental-mode run")
     ap.add_argument("--no-mode-b", action="store_true", help="skip the extra Mode B (super-step) run")
+    ap.add_argument("--extras-multi", action="store_true",
+                    help="also run the exact-incremental extra at N > 1 (default: N = 1 only, the scaling runs time the full-sweep loop alone)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-process code path (gloo rendezvous + RCCL communicator) even with one rank")
@@ -188,7 +190,7 @@ def main():
 
     # ---- after the timed region: the same loop in exact incremental mode (reported beside `value`, never as it)
     inc = None
-    if not a.no_incremental:
+    if not a.no_incremental and (N == 1 or a.extras_multi):
         run.np_pos += r["np_used"]
         inc_inputs = prepare(step + a.steps, a.steps)
         barrier()

@@ -122,11 +122,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(SO_PATH):
+    so_path = os.environ.get("CETKMC_LIB", SO_PATH)       # alternative build of the same library (A/B timing only)
+    if not os.path.exists(so_path):
         raise RuntimeError(
-            f"{SO_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{so_path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  cetkmc has no CPU fallback.")
-    lib = C.CDLL(SO_PATH)
+    lib = C.CDLL(so_path)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)
         fn.restype = res

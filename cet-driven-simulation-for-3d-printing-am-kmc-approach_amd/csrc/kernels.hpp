@@ -41,6 +41,12 @@ struct BatchCfg {
     int32_t batch;      // 1: r = u_pick[cur]*total and RNG bookkeeping; 0: direct r
 };
 
+#ifndef CETKMC_SWEEP_UNROLL
+#define CETKMC_SWEEP_UNROLL 2      // voxels of a lane's 4 evaluated per trip of the per-voxel loop (4: 137 VGPRs, 3 waves/SIMD)
+#endif
+#ifndef CETKMC_SWEEP_ATTR
+#define CETKMC_SWEEP_ATTR          // e.g. __attribute__((amdgpu_waves_per_eu(4, 4))) for A/B builds
+#endif
 constexpr int SWEEP_TJ = 8;        // rows of one plane per sweep block
 constexpr int PMAX = 2048;         // max leaves of an LDS heap tree (3L <= PMAX)
 
@@ -264,7 +270,7 @@ __device__ __forceinline__ void sweep_row(const StreamArgs& A, const double* kta
             double p0 = 0.0, p1 = 0.0, p2 = 0.0;             // even voxel of the current pair
             double pw = 0.0;                                 // WV: value / count of the even voxel
             unsigned pc = 0;
-#pragma unroll 2
+#pragma unroll CETKMC_SWEEP_UNROLL
             for (int h = 0; h < 4; ++h) {
                 const int sh = 16 * (h & 1);
                 const unsigned f = ((h < 2 ? acc.x : acc.y) >> sh) & 0xFFFFu;
@@ -340,7 +346,7 @@ __device__ __forceinline__ void sweep_row(const StreamArgs& A, const double* kta
 }
 
 template <int TJ, bool WV>
-__global__ __launch_bounds__(256) void k_sweep_stream(StreamArgs A, const double* __restrict__ ktab_g,
+__global__ __launch_bounds__(256) CETKMC_SWEEP_ATTR void k_sweep_stream(StreamArgs A, const double* __restrict__ ktab_g,
                                                       const StepState* __restrict__ ss)
 {
     if (ss && ss->status) return;

@@ -136,7 +136,11 @@ __device__ __forceinline__ double dep_rate(const KParams& P, double Tc)
 __device__ __forceinline__ double fma1(double a, double b, double c)
 {
     double d;
+#ifdef CETKMC_EXP_SGPR
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+#else
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+#endif
     return d;
 }
 __device__ __forceinline__ double exp_nonpos(double x)
