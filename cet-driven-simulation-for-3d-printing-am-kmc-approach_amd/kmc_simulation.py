@@ -117,6 +117,7 @@ def run_kmc(
     checkpoint_every: int = 0,
     resume_from: str = None,
     incremental: bool = True,
+    nu_dep: float = None,
 ):
     """KMC microstructure evolution with natural defect injection (same contract as the
     reference).  ``defect_fraction`` is the per-event probability that the just-updated voxel
@@ -126,7 +127,9 @@ def run_kmc(
     ``outputs/<prefix>/checkpoint.npz`` every k steps; ``resume_from=path`` continues such a run --
     the continued run is bit-identical to an uninterrupted one (lattice, time, CSV, RNG streams);
     ``incremental=False`` re-evaluates the whole lattice on every step like get_event_rates does (the
-    default re-evaluates only the rows an event made stale between temperature updates -- same results)."""
+    default re-evaluates only the rows an event made stale between temperature updates -- same results);
+    ``nu_dep`` overrides constants.NU_DEP (deposition attempt frequency = growth velocity V of the G-V sweep
+    driver gv_sweep.py; the reference can only change it by editing constants.py)."""
     import cetkmc
 
     output_dir = f"outputs/{output_prefix}"
@@ -144,12 +147,15 @@ def run_kmc(
             lattice_size=L, n_seeds=n_seeds, T_sub=temp, impurity_c=impurity_c)
         defects_mask, defect_density = introduce_defects(state, atom_type, T, apply_to_state=False)
 
+    nu_dep_eff = NU_DEP if nu_dep is None else float(nu_dep)
     G = (T_MELT - T_SUB) / (L * VOXEL_SIZE)
-    R = NU_DEP * 2.74e-10 / VOXEL_SIZE
-    R_phys = NU_DEP * ATOMIC_SPACING_W
+    R = nu_dep_eff * 2.74e-10 / VOXEL_SIZE
+    R_phys = nu_dep_eff * ATOMIC_SPACING_W
     G_over_R_phys = G / R_phys
 
-    engine = cetkmc.Engine(L, impurity_c=impurity_c)
+    params = cetkmc.default_params(impurity_c)
+    params.nu_dep = nu_dep_eff
+    engine = cetkmc.Engine(L, impurity_c=impurity_c, params=params)
     engine.upload(state, theta, phi, T, defects_mask)
     n_flagged = int(np.sum(defects_mask))
 

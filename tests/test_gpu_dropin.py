@@ -150,3 +150,24 @@ def test_checkpoint_resume_is_bit_identical(tmp_path, monkeypatch):
     a = pd.read_csv("outputs/full/metrics.csv")
     b = pd.read_csv("outputs/part/metrics.csv")
     assert a.equals(b)
+
+
+def test_gv_sweep_driver(tmp_path, monkeypatch, capsys):
+    """gv_sweep.py (BASELINE config 5 driver): substrate temperature and deposition frequency reach the engine
+    (G and R columns follow them, deposition events follow nu_dep), one map row per (T_sub, nu_dep)."""
+    import constants
+    import gv_sweep
+    monkeypatch.chdir(tmp_path)
+    df = gv_sweep.gv_sweep(L=10, n_steps=45, temps=(2800.0, 3300.0), nu_deps=(2e13, 2e15), carbon=0.2)
+    capsys.readouterr()
+    assert len(df) == 4 and os.path.exists("outputs/gv_sweep/gv_map.csv")
+    assert sorted(set(df["V_m_per_s"])) == [2e13 * constants.ATOMIC_SPACING_W, 2e15 * constants.ATOMIC_SPACING_W]
+    m = pd.read_csv("outputs/gv_sweep/T3300_V2e+15_c_20/metrics.csv")
+    assert np.allclose(m["R_phys"], 2e15 * constants.ATOMIC_SPACING_W)
+    # default nu_dep reproduces the plain run_kmc of the same arguments
+    import kmc_simulation
+    a = kmc_simulation.run_kmc(L=10, n_steps=45, temp=2800.0, defect_fraction=constants.DEFECT_PROB, n_seeds=constants.N_SEEDS,
+                               impurity_c=0.2, output_prefix="plain")
+    b = pd.read_csv("outputs/gv_sweep/T2800_V2e+13_c_20/metrics.csv")
+    assert b.equals(pd.read_csv("outputs/plain/metrics.csv"))
+    assert a[0].shape == (10, 10, 10)
