@@ -425,7 +425,7 @@ int launch_interface(Handle* h, bool batch, hipStream_t st, bool long_list = fal
     const StepState* ss = batch ? h->d_ss : nullptr;
     for (size_t s = 0; s < h->slabs.size(); ++s)
         if (long_list)
-            hipLaunchKernelGGL(k_interface_part, dim3(2048), dim3(256), 0, st, h->kp, view_of(h, (int)s), h->d_ktab, ss);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_interface_part<1024>), dim3(2048), dim3(256), 0, st, h->kp, view_of(h, (int)s), h->d_ktab, ss);
         else
             hipLaunchKernelGGL(k_interface, dim3(h->ifc_blocks * (256 / h->ifc_block)), dim3(h->ifc_block), 0, st, h->kp,
                            view_of(h, (int)s), h->d_ktab, ss);

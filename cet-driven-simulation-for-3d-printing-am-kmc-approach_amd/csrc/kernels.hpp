@@ -833,7 +833,7 @@ __global__ __launch_bounds__(256) void k_interface(KParams P, SlabView S, const 
 // Same results for long lists (Mode B, where most of the lattice becomes interface): a block takes tiles of
 // 1024 entries, sorts them by kind (empty / atom) into two LDS queues and evaluates each queue with full
 // waves, so that a wave runs only one of the two (expensive, differently shaped) rate loops.
-constexpr int IFC_TILE = 1024;
+template <int IFC_TILE>
 __global__ __launch_bounds__(256) void k_interface_part(KParams P, SlabView S, const double* __restrict__ ktab_g,
                                                         const StepState* __restrict__ ss)
 {
