@@ -111,6 +111,12 @@ def main():
     if L % N:
         raise SystemExit(f"L={L} not divisible by {N} ranks")
 
+    # Libraries chat on stdout (gloo's "[Gloo] Rank ..." line, RCCL's version banner under NCCL_DEBUG): keep fd 1 for
+    # the ONE JSON line -- everything else goes to stderr until the result is printed.
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import cetkmc
     from cetkmc import synthetic
 
@@ -125,7 +131,9 @@ def main():
         box = [cetkmc.Engine.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         uid = box[0]
-        eng = cetkmc.Engine(L, impurity_c=IMPURITY_C, device=local_rank, rank=rank, nranks=N, unique_id=uid)
+        # one GPU per rank; if the launcher narrowed device visibility to one GPU per process, that GPU is index 0
+        dev = local_rank % max(1, cetkmc.device_count())
+        eng = cetkmc.Engine(L, impurity_c=IMPURITY_C, device=dev, rank=rank, nranks=N, unique_id=uid)
     else:
         eng = cetkmc.Engine(L, impurity_c=IMPURITY_C, device=0)
 
@@ -279,8 +287,12 @@ def main():
         out["incremental_exact"] = inc
     if mode_b is not None:
         out["mode_b"] = mode_b
+    sys.stdout.flush()
+    os.dup2(stdout_fd, 1)
+    os.close(stdout_fd)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    os.dup2(2, 1)                # teardown messages (communicator destruction) stay off stdout as well
     eng.close()
     if dist is not None:
         dist.destroy_process_group()

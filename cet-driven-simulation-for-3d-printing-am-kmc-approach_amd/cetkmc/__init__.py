@@ -5,4 +5,4 @@ thermal_solver.py, ...) keep the reference's names and call signatures and are b
 :class:`cetkmc.engine.Engine`.  There is no CPU fallback: loading fails loudly when the
 shared library is missing, and every compute call fails when no GPU is present.
 """
-from .engine import Engine, Event, default_params, build_library, library_path  # noqa: F401
+from .engine import Engine, Event, default_params, device_count, build_library, library_path  # noqa: F401

@@ -46,6 +46,14 @@ def _dptr(a):
     return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+def device_count():
+    """Number of HIP devices this process can see (0 when there is none)."""
+    n = C.c_int(0)
+    if _lib.load().cetkmc_device_count(C.byref(n)):
+        return 0
+    return n.value
+
+
 class Engine:
     """Owns a cetkmc handle.  ``n_slabs>1`` splits the lattice into axis-0 slabs on the same
     GPU (decomposition check); ``rank/nranks/unique_id`` selects the one-process-per-GPU
