@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-incremental", action="store_true", help="skip the extra exact-incremental-mode run")
     ap.add_argument("--no-mode-b", action="store_true", help="skip the extra Mode B (super-step) run")
+    ap.add_argument("--no-phases", action="store_true", help="skip the extra per-phase timing run")
     ap.add_argument("--extras-multi", action="store_true",
                     help="also run the exact-incremental extra at N > 1 (default: N = 1 only, the scaling runs time the full-sweep loop alone)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
@@ -196,14 +197,31 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
 
-    # ---- after the timed region: the same loop in exact incremental mode (reported beside `value`, never as it)
+    # ---- after the timed region: per-phase device time (hipEvents at every phase boundary, cetkmc_get_counters)
+    run.np_pos += r["np_used"]
+    phases = None
+    if not a.no_phases and (N == 1 or a.extras_multi):
+        n_ph = min(200, a.steps)
+        ph_inputs = prepare(step + a.steps, n_ph)
+        eng.counters(reset=True)
+        rp = run(step + a.steps, n_ph, profile=2, prep=ph_inputs)
+        c = eng.counters()
+        run.np_pos += rp["np_used"]
+        if rp["done"] == n_ph and c["profiled_steps"] == n_ph:
+            phases = {k[3:] + "_us_per_step": 1e3 * c[k] / n_ph for k in ("ms_thermal", "ms_interface", "ms_sweep", "ms_reduce",
+                                                                           "ms_select_apply")}
+            phases.update(steps=n_ph, device_us_per_step=1e3 * rp["wall_ms"] / n_ph,
+                          alg_bytes_per_step=(c["alg_bytes_sweep"] + c["alg_bytes_thermal"]) / n_ph,
+                          note="full-sweep loop, hipEvents at every phase boundary (slower than the timed run by the event "
+                               "records); thermal averaged over its 1-in-20 cadence")
+
+    # ---- the same loop in exact incremental mode (reported beside `value`, never as it)
     inc = None
     if not a.no_incremental and (N == 1 or a.extras_multi):
-        run.np_pos += r["np_used"]
-        inc_inputs = prepare(step + a.steps, a.steps)
+        inc_inputs = prepare(step + 2 * a.steps, a.steps)
         barrier()
         t1 = time.perf_counter()
-        ri = run(step + a.steps, a.steps, prep=inc_inputs, incremental=True)
+        ri = run(step + 2 * a.steps, a.steps, prep=inc_inputs, incremental=True)
         barrier()
         dti = time.perf_counter() - t1
         if dist is not None:
@@ -221,7 +239,7 @@ def main():
     # ---- Mode B (super-steps over 8^3 boxes; not the reference's trajectory, own CPU comparator): executed events/s
     mode_b = None
     if N == 1 and not a.no_mode_b and L % 8 == 0:
-        sb, nb_steps = step + 2 * a.steps, 40
+        sb, nb_steps = step + 3 * a.steps, 40
         qb = synthetic.laser_planes(L, sb, nb_steps)
         eng.sync()
         t2 = time.perf_counter()
@@ -283,6 +301,8 @@ def main():
                             "cores": 1, "sample": f"first {s1} steps, scalar port ({sec1:.1f} s)"},
             "host_cores_available": os.cpu_count(), "parity_first_steps": base["parity"],
         }
+    if phases is not None:
+        out["phases"] = phases
     if inc is not None:
         out["incremental_exact"] = inc
     if mode_b is not None:

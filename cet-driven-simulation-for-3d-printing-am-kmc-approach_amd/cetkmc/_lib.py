@@ -52,6 +52,12 @@ class SuperArgs(C.Structure):
     ]
 
 
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("steps", "sweeps", "incremental_steps", "thermal_updates", "supersteps", "bytes_h2d",
+                                         "bytes_d2h", "alg_bytes_sweep", "alg_bytes_thermal", "profiled_steps")] + \
+               [(n, C.c_double) for n in ("ms_thermal", "ms_interface", "ms_sweep", "ms_dirty_rows", "ms_reduce", "ms_select_apply")]
+
+
 class RunResult(C.Structure):
     _fields_ = [
         ("steps_done", C.c_int64), ("status", C.c_int32), ("np_used", C.c_int64), ("q_used", C.c_int64),
@@ -89,6 +95,7 @@ PROTOTYPES = {
     "cetkmc_row_sums": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cetkmc_run_steps": (C.c_int, [C.c_void_p, _P(RunArgs), _P(RunResult), C.c_void_p, C.c_void_p, C.c_void_p]),
     "cetkmc_run_supersteps": (C.c_int, [C.c_void_p, _P(SuperArgs), _P(RunResult), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cetkmc_get_counters": (C.c_int, [C.c_void_p, _P(Counters), C.c_int]),
     "cetkmc_cluster": (C.c_int, [C.c_void_p, C.c_double, _P(C.c_int64)]),
     "cetkmc_cluster_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cetkmc_cluster_labels": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import Event, Params, RunArgs, RunResult, SuperArgs, SweepInfo, build_library  # noqa: F401
+from ._lib import Counters, Event, Params, RunArgs, RunResult, SuperArgs, SweepInfo, build_library  # noqa: F401
 
 EVENT_DTYPE = np.dtype([("type", "<i4"), ("pos", "<i4", 3), ("target", "<i4", 3), ("atom", "<i4"),
                         ("rate", "<f8"), ("dep_rank", "<i8"), ("theta", "<f8"), ("phi", "<f8")], align=True)
@@ -246,7 +246,7 @@ class Engine:
         a.np_cap, a.rng_mode, a.seed = len(u_np), int(rng_mode), int(seed)
         a.thermal_mode, a.thermal_dt = int(thermal_mode), float(thermal_dt)
         a.q_planes, a.n_q = _dptr(q), (0 if q is None else q.shape[0])
-        a.use_latent, a.profile = int(bool(use_latent)), int(bool(profile))
+        a.use_latent, a.profile = int(bool(use_latent)), int(profile)       # profile: False/True/2 (per-phase, see counters())
         a.incremental = int(bool(incremental))
         res = RunResult()
         totals = np.zeros(n + 1, np.float64) if want_logs else None
@@ -260,6 +260,12 @@ class Engine:
         if want_logs:
             out.update(totals=totals[:done + (1 if res.status == 1 else 0)], events=events[:done], n_events=nev[:done])
         return out
+
+    def counters(self, reset=False):
+        """cetkmc_get_counters as a dict: work issued, bytes moved, per-phase device ms of the profile=2 runs."""
+        c = Counters()
+        self._ck(self.lib.cetkmc_get_counters(self.h, C.byref(c), int(bool(reset))))
+        return {n: getattr(c, n) for n, _ in Counters._fields_}
 
     # -- Mode B: synchronous super-steps over (L/box)^3 boxes (not in the reference; include/cetkmc.h) --------
     def run_supersteps(self, step0, n, box, defect_fraction, seed, thermal_mode=1, thermal_dt=1e-6, q_planes=None,

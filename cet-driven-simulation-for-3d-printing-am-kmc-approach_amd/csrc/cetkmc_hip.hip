@@ -135,6 +135,7 @@ struct Handle {
     int64_t cc_n_clusters = -1;
     std::vector<int> cc_roots_sorted;
     std::vector<hipEvent_t> prof;
+    cetkmc_counters cnt{};       // cetkmc_get_counters: work issued / bytes moved / per-phase device time
 };
 
 KParams make_kparams(const cetkmc_params& p)
@@ -309,6 +310,7 @@ int h2d_f64(Handle* h, const Slab& s, double* dst, const double* src, int i_begi
 {
     const int L = h->L;
     const int li = a - (s.v.gi0 - 2);
+    h->cnt.bytes_h2d += (int64_t)(b - a) * L * L * 8;
     HIPCHK(hipMemcpy2DAsync(dst + (size_t)li * L * h->pitchT, (size_t)h->pitchT * 8,
                             src + (size_t)(a - i_begin) * L * L, (size_t)L * 8, (size_t)L * 8,
                             (size_t)(b - a) * L, hipMemcpyHostToDevice, h->stream));
@@ -318,6 +320,7 @@ int d2h_f64(Handle* h, const Slab& s, const double* srcd, double* dst, int i_beg
 {
     const int L = h->L;
     const int li = a - (s.v.gi0 - 2);
+    h->cnt.bytes_d2h += (int64_t)(b - a) * L * L * 8;
     HIPCHK(hipMemcpy2DAsync(dst + (size_t)(a - i_begin) * L * L, (size_t)L * 8,
                             srcd + (size_t)li * L * h->pitchT, (size_t)h->pitchT * 8, (size_t)L * 8,
                             (size_t)(b - a) * L, hipMemcpyDeviceToHost, h->stream));
@@ -330,6 +333,7 @@ int h2d_u8(Handle* h, const Slab& s, uint8_t* dst, const SRC* src, int i_begin, 
     const int L = h->L;
     const size_t n = (size_t)(b - a) * L * L;
     CHK(ensure_scratch(h, n * sizeof(SRC)));
+    h->cnt.bytes_h2d += (int64_t)(n * sizeof(SRC));
     HIPCHK(hipMemcpyAsync(h->d_scratch, src + (size_t)(a - i_begin) * L * L, n * sizeof(SRC), hipMemcpyHostToDevice, h->stream));
     const int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
     if (check) {
@@ -356,6 +360,7 @@ int d2h_u8(Handle* h, const Slab& s, const uint8_t* srcd, DST* dst, int i_begin,
     const int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_unpack_u8<DST>), dim3(grid), dim3(256), 0, h->stream, s.v, srcd, (DST*)h->d_scratch, a, b - a);
     HIPCHK(hipGetLastError());
+    h->cnt.bytes_d2h += (int64_t)(n * sizeof(DST));
     HIPCHK(hipMemcpyAsync(dst + (size_t)(a - i_begin) * L * L, h->d_scratch, n * sizeof(DST), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
@@ -467,8 +472,11 @@ int launch_dirty_rows(Handle* h, hipEvent_t ev_a, hipEvent_t ev_b)
 }
 
 int launch_sweep(Handle* h, bool batch, hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr, bool skip_ifc = false,
-                 bool write_vox = false)
+                 bool write_vox = false, hipEvent_t ev_pre = nullptr, hipEvent_t ev_post = nullptr)
 {
+    ++h->cnt.sweeps;
+    for (auto& sl : h->slabs) h->cnt.alg_bytes_sweep += (int64_t)10 * sl.v.nloc * h->L * h->L;   // cls u16 + T f64 per voxel
+    if (ev_pre) HIPCHK(hipEventRecord(ev_pre, h->stream));
     const int TR = SWEEP_TJ + 4;
     const size_t shmem0 = (size_t)((5 * TR * h->pitchS + 15) & ~15) + 225 * sizeof(double);
     const StepState* ss = batch ? h->d_ss : nullptr;
@@ -503,6 +511,7 @@ int launch_sweep(Handle* h, bool batch, hipEvent_t ev_a = nullptr, hipEvent_t ev
         const size_t per = (size_t)3 * (h->L / h->nranks) * sizeof(BlockEnt);
         NCCLCHK(g_rccl.AllGather((const char*)h->d_blocks + per * h->rank, h->d_blocks, per, ncclChar, h->comm, h->stream));
     }
+    if (ev_post) HIPCHK(hipEventRecord(ev_post, h->stream));
     h->swept = true;
     return 0;
 }
@@ -577,6 +586,8 @@ int launch_thermal(Handle* h, double dt, int laser, const double* d_q, int use_l
     C.dt = dt; C.alpha = h->p.alpha; C.inv_dx2 = h->p.inv_dx2; C.clip_lo = h->p.T_clip_lo; C.clip_hi = h->p.T_clip_hi;
     C.T_nan = h->p.T_nan; C.rho_cp = h->p.rho_cp; C.latent_coef = h->p.latent_coef;
     C.laser = laser; C.use_latent = use_latent; C.scrub = scrub; C.ni = h->therm_ni;
+    ++h->cnt.thermal_updates;
+    for (auto& sl : h->slabs) h->cnt.alg_bytes_thermal += (int64_t)16 * sl.v.nloc * h->L * h->L;   // T read + written
     const int nxt = h->cur ^ 1;
     for (size_t s = 0; s < h->slabs.size(); ++s) {
         SlabView v = view_of(h, (int)s);
@@ -999,9 +1010,17 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
     BatchCfg cfg{};
     cfg.step0 = a->step0; cfg.np_cap = a->np_cap; cfg.defect_fraction = a->defect_fraction; cfg.seed = a->seed;
     cfg.rng_mode = a->rng_mode; cfg.batch = 1;
+    // profile 1: two events per step around the rate-sweep kernel (bench roofline); profile 2: seven per step
+    // (thermal | interface | sweep | reduce(+all-gather) | select+apply boundaries) for cetkmc_get_counters
+    const int EPS = a->profile == 2 ? 7 : 2;
     if (a->profile) {
-        while ((int64_t)h->prof.size() < 2 * n) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->prof.push_back(e); }
+        while ((int64_t)h->prof.size() < EPS * n) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->prof.push_back(e); }
     }
+    auto pev = [&](int64_t s, int q) -> hipEvent_t { return a->profile == 2 ? h->prof[EPS * s + q] : nullptr; };
+    std::vector<char> was_thermal, was_full;
+    if (a->profile == 2) { was_thermal.assign((size_t)n, 0); was_full.assign((size_t)n, 0); }
+    h->cnt.bytes_h2d += (n > 0 ? n * 8 : 0) + (n > 0 && a->u_defect ? n * 8 : 0) + std::max<int64_t>(a->np_cap, 0) * 8 +
+                        (a->thermal_mode == 2 ? n_therm * (int64_t)L2 * 8 : 0);
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     int64_t q_idx = 0;
     bool ifc_fresh = false;     // ifc_val already holds this step's interface sums (speculative launch of the previous step)
@@ -1012,18 +1031,30 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
         const bool therm = a->thermal_mode && g % 20 == 0;
         if (incr && s > 0 && !therm) {
             // exact incremental step: rates can only have changed in the rows recorded by the last apply
-            CHK(launch_dirty_rows(h, a->profile ? h->prof[2 * s] : nullptr, a->profile ? h->prof[2 * s + 1] : nullptr));
-            CHK(launch_select_apply(h, cfg, 1, h->d_dirty));
+            ++h->cnt.incremental_steps;
+            if (a->profile == 2) {
+                HIPCHK(hipEventRecord(pev(s, 2), h->stream));
+                CHK(launch_dirty_rows(h, nullptr, pev(s, 3)));
+                HIPCHK(hipEventRecord(pev(s, 4), h->stream));
+                CHK(launch_select_apply(h, cfg, 1, h->d_dirty));
+                HIPCHK(hipEventRecord(pev(s, 5), h->stream));
+            } else {
+                CHK(launch_dirty_rows(h, a->profile ? h->prof[2 * s] : nullptr, a->profile ? h->prof[2 * s + 1] : nullptr));
+                CHK(launch_select_apply(h, cfg, 1, h->d_dirty));
+            }
             h->swept = false;
             continue;
         }
         ++res->full_sweeps;
+        if (a->profile == 2) { was_full[s] = 1; HIPCHK(hipEventRecord(pev(s, 0), h->stream)); }
         if (a->thermal_mode && g % 20 == 0) {
             if (a->thermal_mode == 1) CHK(launch_thermal(h, a->thermal_dt, 0, nullptr, 0, 1, true));
             else { CHK(launch_thermal(h, a->thermal_dt, 1, h->d_q + (size_t)q_idx * L2, a->use_latent, 1, true)); ++q_idx; }
             ifc_fresh = false;  // T changed
+            if (a->profile == 2) was_thermal[s] = 1;
         }
-        if (a->profile) CHK(launch_sweep(h, true, h->prof[2 * s], h->prof[2 * s + 1], ifc_fresh));
+        if (a->profile == 2) CHK(launch_sweep(h, true, pev(s, 2), pev(s, 3), ifc_fresh, false, pev(s, 1), pev(s, 4)));
+        else if (a->profile) CHK(launch_sweep(h, true, h->prof[2 * s], h->prof[2 * s + 1], ifc_fresh));
         else CHK(launch_sweep(h, true, nullptr, nullptr, ifc_fresh));
         // Overlap: the interface sums of step s+1 are evaluated on a second stream while this step reduces
         // and selects; the apply kernel then re-evaluates the <= 30 listed voxels the event touches, so
@@ -1045,6 +1076,7 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
         } else {
             CHK(launch_select_apply(h, cfg, incr ? 1 : 0, incr ? h->d_dirty : nullptr));
         }
+        if (a->profile == 2) HIPCHK(hipEventRecord(pev(s, 5), h->stream));
         ifc_fresh = spec;
         h->swept = false;
     }
@@ -1058,7 +1090,32 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     res->wall_ms = ms;
     res->sweep_ms_total = 0.0; res->sweep_launches = 0;
-    if (a->profile) {
+    if (a->profile == 2) {
+        auto el = [&](int64_t s, int qa, int qb, double* acc) -> int {
+            float t = 0.f;
+            HIPCHK(hipEventElapsedTime(&t, h->prof[EPS * s + qa], h->prof[EPS * s + qb]));
+            *acc += t;
+            return 0;
+        };
+        for (int64_t s = 0; s < n; ++s) {
+            if (was_full[s]) {
+                if (was_thermal[s]) CHK(el(s, 0, 1, &h->cnt.ms_thermal));
+                CHK(el(s, 1, 2, &h->cnt.ms_interface));
+                CHK(el(s, 2, 3, &h->cnt.ms_sweep));
+                CHK(el(s, 3, 4, &h->cnt.ms_reduce));
+                CHK(el(s, 4, 5, &h->cnt.ms_select_apply));
+                double t = 0.0;
+                CHK(el(s, 2, 3, &t));
+                res->sweep_ms_total += t;
+                ++res->sweep_launches;
+            } else {
+                CHK(el(s, 2, 3, &h->cnt.ms_dirty_rows));
+                CHK(el(s, 3, 4, &h->cnt.ms_reduce));
+                CHK(el(s, 4, 5, &h->cnt.ms_select_apply));
+            }
+        }
+        h->cnt.profiled_steps += n;
+    } else if (a->profile) {
         for (int64_t s = 0; s < n; ++s) {
             float t = 0.f;
             HIPCHK(hipEventElapsedTime(&t, h->prof[2 * s], h->prof[2 * s + 1]));
@@ -1066,12 +1123,23 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
         }
         res->sweep_launches = n;
     }
+    h->cnt.steps += ss.cur;
     const int64_t done = ss.cur;
     const int64_t nt = done + (ss.status == 1 ? 1 : 0);
     if (totals && done > 0) HIPCHK(hipMemcpy(totals, h->d_log_total, (size_t)done * 8, hipMemcpyDeviceToHost));
     if (totals && ss.status == 1 && nt <= n) totals[done] = ss.total;
     if (events && done > 0) HIPCHK(hipMemcpy(events, h->d_log_event, (size_t)done * sizeof(cetkmc_event), hipMemcpyDeviceToHost));
     if (n_events && done > 0) HIPCHK(hipMemcpy(n_events, h->d_log_nev, (size_t)done * 8, hipMemcpyDeviceToHost));
+    h->cnt.bytes_d2h += (totals ? done * 8 : 0) + (events ? done * (int64_t)sizeof(cetkmc_event) : 0) + (n_events ? done * 8 : 0);
+    return 0;
+}
+
+int cetkmc_get_counters(void* handle, cetkmc_counters* out, int reset)
+{
+    Handle* h = (Handle*)handle;
+    if (!h || !out) return fail("null argument");
+    *out = h->cnt;
+    if (reset) h->cnt = cetkmc_counters{};
     return 0;
 }
 
@@ -1162,6 +1230,7 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     res->wall_ms = ms; res->sweep_ms_total = 0.0; res->sweep_launches = 0; res->full_sweeps = n;
+    h->cnt.supersteps += ss.cur;
     const int64_t done = ss.cur;
     if (totals && done > 0) HIPCHK(hipMemcpy(totals, h->d_log_total, (size_t)done * 8, hipMemcpyDeviceToHost));
     if (totals && ss.status == 1 && done < n) totals[done] = ss.total;

@@ -99,7 +99,7 @@ typedef struct cetkmc_run_args {
     const double* q_planes;   /* thermal_mode 2: [n_q][L*L] source planes, consumed in order */
     int64_t n_q;
     int32_t use_latent;       /* thermal_mode 2: latent-heat term on/off                */
-    int32_t profile;          /* 1: time every rate-sweep launch with hipEvents         */
+    int32_t profile;          /* 1: time every rate-sweep launch with hipEvents; 2: time every phase (cetkmc_get_counters) */
     int32_t incremental;      /* 0: every step evaluates the whole lattice (get_event_rates, kmc_event_rates.py:162);
                                  1: exact incremental mode -- between temperature updates only the rows whose
                                     rates the previous event can have changed are re-evaluated (identical
@@ -135,6 +135,21 @@ typedef struct cetkmc_super_args {
     int64_t n_q;
     int32_t use_latent;
 } cetkmc_super_args;
+
+/* Work issued, bytes moved and (while cetkmc_run_args.profile == 2) device time per phase, accumulated on the
+ * handle since creation / the last reset.  Algorithmic bytes: 10 B per owned voxel per rate sweep (class u16 +
+ * T f64), 16 B per owned voxel per temperature update. */
+typedef struct cetkmc_counters {
+    int64_t steps;              /* batched Mode A steps executed (cetkmc_run_steps)               */
+    int64_t sweeps;             /* full rate sweeps launched (any entry point)                     */
+    int64_t incremental_steps;  /* steps that re-evaluated dirty rows only                         */
+    int64_t thermal_updates;
+    int64_t supersteps;         /* Mode B super-steps executed                                     */
+    int64_t bytes_h2d, bytes_d2h;               /* host <-> device bytes moved by this handle       */
+    int64_t alg_bytes_sweep, alg_bytes_thermal; /* algorithmic bytes of the work issued             */
+    int64_t profiled_steps;     /* steps the ms_* fields below cover                               */
+    double  ms_thermal, ms_interface, ms_sweep, ms_dirty_rows, ms_reduce, ms_select_apply;
+} cetkmc_counters;
 
 const char* cetkmc_last_error(void);
 int cetkmc_abi_version(void);
@@ -205,6 +220,8 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* args, cetkmc_run_resul
  * n_executed[n] events applied per super-step.  res->np_used is 0; single process only. */
 int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_result* res, double* totals,
                           cetkmc_event* events, int64_t* n_executed);
+
+int cetkmc_get_counters(void* handle, cetkmc_counters* out, int reset);
 
 /* Grain clustering on the device (utils.get_clusters / dfs_cluster, utils.py:28-84): connected
  * components of occupied 14-stencil neighbours with misorientation < threshold, numbered 1.. in the

@@ -518,3 +518,33 @@ def test_incremental_mode_large_rows_and_laser():
         outs.append((r["totals"].tobytes(), r["events"].tobytes(), e.rate_sweep(), e.row_sums()[0].tobytes()))
         e.close()
     assert outs[0] == outs[1]
+
+
+def test_counters_and_phase_profile():
+    """cetkmc_get_counters: work issued, bytes moved, and the per-phase device times of a profile=2 batch;
+    profiling must not change results."""
+    L = 48
+    state, theta, phi, T, defects = random_lattice(L, 5, fill=0.2)
+    rs = np.random.RandomState(2)
+    n = 60
+    u_pick, u_def, u_np = rs.random_sample(n), rs.random_sample(n), rs.random_sample(n * (L * L + 2))
+    outs = []
+    for prof, inc in ((False, False), (2, False), (2, True)):
+        e = _engine(L, 0.2)
+        e.upload(state, theta, phi, T, defects)
+        c0 = e.counters(reset=True)
+        assert c0["bytes_h2d"] == L ** 3 * (8 + 8 + 8 + 8 + 8)          # int64 state/defects + three f64 fields
+        r = e.run_steps(0, n, 0.05, u_pick, u_def, u_np, rng_mode=0, thermal_mode=1, profile=prof, incremental=inc)
+        c = e.counters()
+        assert r["done"] == n and c["steps"] == n and c["thermal_updates"] == 3
+        assert c["sweeps"] == (n if not inc else 3) and c["incremental_steps"] == (0 if not inc else n - 3)
+        assert c["alg_bytes_sweep"] == c["sweeps"] * 10 * L ** 3 and c["alg_bytes_thermal"] == 3 * 16 * L ** 3
+        if prof == 2:
+            assert c["profiled_steps"] == n
+            assert c["ms_sweep"] > 0 and c["ms_interface"] > 0 and c["ms_select_apply"] > 0 and c["ms_thermal"] > 0
+            assert (c["ms_dirty_rows"] > 0) == inc
+            parts = sum(c[k] for k in ("ms_thermal", "ms_interface", "ms_sweep", "ms_dirty_rows", "ms_reduce", "ms_select_apply"))
+            assert 0.5 * r["wall_ms"] < parts <= 1.05 * r["wall_ms"]
+        outs.append((r["totals"].tobytes(), r["events"].tobytes(), e.download()["theta"].tobytes()))
+        e.close()
+    assert outs[0] == outs[1] == outs[2]
