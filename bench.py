@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--no-incremental", action="store_true", help="skip the extra exact-incremental-mode run")
     ap.add_argument("--no-mode-b", action="store_true", help="skip the extra Mode B (super-step) run")
     ap.add_argument("--no-phases", action="store_true", help="skip the extra per-phase timing run")
+    ap.add_argument("--overlap-interface", type=int, default=-1,
+                    help="speculative interface evaluation of the next step during select/collectives: 1 on, 0 off (default: engine default = off)")
     ap.add_argument("--extras-multi", action="store_true",
                     help="also run the exact-incremental extra at N > 1 (default: N = 1 only, the scaling runs time the full-sweep loop alone)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
@@ -137,6 +139,9 @@ def main():
         eng = cetkmc.Engine(L, impurity_c=IMPURITY_C, device=dev, rank=rank, nranks=N, unique_id=uid)
     else:
         eng = cetkmc.Engine(L, impurity_c=IMPURITY_C, device=0)
+
+    if a.overlap_interface >= 0:
+        eng.set_option("overlap_interface", a.overlap_interface)
 
     # ---- synthetic input, resident in HBM before anything is timed -----------------------
     a0, a1 = max(0, eng.i0 - 2), min(L, eng.i1 + 2)

@@ -97,7 +97,9 @@ struct Handle {
     int dev = 0;
     hipStream_t stream = nullptr, stream2 = nullptr;
     hipEvent_t ev_swept = nullptr, ev_ifc = nullptr;
-    int overlap_ifc = 0;       // speculative k_interface of step s+1 overlapped with reduce/select of step s (measured: no gain)
+    int overlap_ifc = 0;       // speculative k_interface of step s+1 overlapped with reduce/select of step s: costs ~18 us per
+                               // step on one GPU (event syncs + touched-voxel re-evaluation); candidate for N > 1, where it
+                               // would run inside the two collectives' latency (bench.py --overlap-interface 1), unmeasured
     std::vector<Slab> slabs;
     SlabView* d_views[2] = {nullptr, nullptr};   // per T-buffer parity
     int cur = 0;                                 // current T buffer
@@ -1059,7 +1061,7 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
         // Overlap: the interface sums of step s+1 are evaluated on a second stream while this step reduces
         // and selects; the apply kernel then re-evaluates the <= 30 listed voxels the event touches, so
         // every listed voxel is still evaluated in full for every step.  Not worth it before a thermal update.
-        const bool spec = h->overlap_ifc && h->sweep_variant == 1 && (s + 1 < n) && !(a->thermal_mode && (g + 1) % 20 == 0);
+        const bool spec = h->overlap_ifc && !incr && h->sweep_variant == 1 && (s + 1 < n) && !(a->thermal_mode && (g + 1) % 20 == 0);
         if (spec) {
             HIPCHK(hipEventRecord(h->ev_swept, h->stream));
             HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_swept, 0));

@@ -118,18 +118,21 @@ def test_rccl_single_rank_mode():
     n = 40
     u_pick, u_def, u_np = rs.random_sample(n), rs.random_sample(n), rs.random_sample(n * (L * L + 2))
     outs = []
-    for mode in ("plain", "rank"):
+    for mode in ("plain", "rank", "rank+overlap", "rank+incremental"):
         if mode == "plain":
             e = cetkmc.Engine(L, impurity_c=0.2)
         else:
             e = cetkmc.Engine(L, impurity_c=0.2, rank=0, nranks=1, unique_id=cetkmc.Engine.unique_id())
+        if mode == "rank+overlap":
+            e.set_option("overlap_interface", 1)
         e.upload(state, theta, phi, T, defects)
-        res = e.run_steps(0, n, 0.05, u_pick, u_def, u_np, rng_mode=0, thermal_mode=1)
+        res = e.run_steps(0, n, 0.05, u_pick, u_def, u_np, rng_mode=0, thermal_mode=1, incremental=(mode == "rank+incremental"))
         outs.append((res["totals"].copy(), res["events"].tobytes(), e.download()))
         e.close()
-    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
-    for k in outs[0][2]:
-        assert np.array_equal(outs[0][2][k], outs[1][2][k])
+    for o in outs[1:]:
+        assert np.array_equal(outs[0][0], o[0]) and outs[0][1] == o[1]
+        for k in outs[0][2]:
+            assert np.array_equal(outs[0][2][k], o[2][k])
 
 
 def test_checkpoint_resume_is_bit_identical(tmp_path, monkeypatch):
