@@ -183,7 +183,9 @@ __device__ __forceinline__ double rcp_nr(double d)
 __device__ __forceinline__ double nuc_rate_s(double I0, double K, double dT, double kTT)
 {
     const double a = dT + 1e-6;
-    const double den = pymax(a * a, 1e-6);
+    // max((dT+1e-6)^2, 1e-6), kmc_event_rates.py:127.  Callers only get here with dT > delta_T_c (never NaN), where
+    // IEEE max and the reference's Python max agree; one v_max_f64 instead of compare + two selects.
+    const double den = fmax(a * a, 1e-6);
     return I0 * exp_nonpos(-K * rcp_nr(den * kTT));
 }
 __device__ __forceinline__ double nuc_rate(const KParams& P, double K, double dT, double kTT)
