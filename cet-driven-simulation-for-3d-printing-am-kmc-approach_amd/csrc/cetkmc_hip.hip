@@ -260,6 +260,8 @@ int create_common(const cetkmc_params* p, int L, const std::vector<std::pair<int
         HIPCHK(hipMemsetAsync(s.v.phi, 0, s.nT * sizeof(double), h->stream));
         HIPCHK(hipMalloc((void**)&s.v.ovec, 3 * s.nT * sizeof(double)));
         HIPCHK(hipMalloc((void**)&s.v.ifc_val, s.nT * sizeof(double)));
+        HIPCHK(hipMalloc((void**)&s.v.dep_val, (size_t)L * h->pitchT * sizeof(double)));
+        HIPCHK(hipMemsetAsync(s.v.dep_val, 0, (size_t)L * h->pitchT * sizeof(double), h->stream));
         HIPCHK(hipMalloc((void**)&s.v.ifc_cnt, s.nT));
         HIPCHK(hipMalloc((void**)&s.v.ifc_in, s.nT));
         HIPCHK(hipMalloc((void**)&s.v.ifc_code, s.nT * sizeof(uint32_t)));
@@ -446,7 +448,7 @@ StreamArgs stream_args(Handle* h, const SlabView& v)
     sa.T_melt = h->kp.T_melt; sa.delta_T_c = h->kp.delta_T_c; sa.kT = h->kp.kT; sa.I0 = h->kp.I0;
     sa.rate_threshold = h->kp.rate_threshold; sa.nu_dep = h->kp.nu_dep;
     sa.L = v.L; sa.gi0 = v.gi0; sa.nloc = v.nloc; sa.RJ = v.RJ; sa.pitchC = v.pitchC; sa.pitchT = v.pitchT; sa.Pk = v.Pk;
-    sa.cls = v.cls; sa.T = v.T; sa.ifc_val = v.ifc_val; sa.ifc_cnt = v.ifc_cnt; sa.rowsum = v.rowsum; sa.rowcnt = v.rowcnt;
+    sa.cls = v.cls; sa.T = v.T; sa.ifc_val = v.ifc_val; sa.ifc_cnt = v.ifc_cnt; sa.dep_val = v.dep_val; sa.rowsum = v.rowsum; sa.rowcnt = v.rowcnt;
     sa.group_first = 0; sa.group_count = (v.nloc + STREAM_NI - 1) / STREAM_NI;
     return sa;
 }
@@ -636,7 +638,7 @@ void destroy_impl(Handle* h)
         (void)hipFree(s.v.state); (void)hipFree(s.v.defects); (void)hipFree(s.prev); (void)hipFree(s.v.cls);
         (void)hipFree(s.Tbuf[0]); (void)hipFree(s.Tbuf[1]); (void)hipFree(s.v.theta); (void)hipFree(s.v.phi); (void)hipFree(s.v.ovec);
         (void)hipFree(s.v.rowsum); (void)hipFree(s.v.rowcnt);
-        (void)hipFree(s.v.ifc_val); (void)hipFree(s.v.ifc_cnt); (void)hipFree(s.v.ifc_in); (void)hipFree(s.v.ifc_code); (void)hipFree(s.v.ifc_list); (void)hipFree(s.v.ifc_n);
+        (void)hipFree(s.v.ifc_val); (void)hipFree(s.v.dep_val); (void)hipFree(s.v.ifc_cnt); (void)hipFree(s.v.ifc_in); (void)hipFree(s.v.ifc_code); (void)hipFree(s.v.ifc_list); (void)hipFree(s.v.ifc_n);
     }
     void* ccp[] = {h->d_cc_parent, h->d_cc_roots, h->d_cc_cid, h->d_cc_labels, h->d_cc_stats, h->d_cc_n};
     for (void* p : ccp) if (p) (void)hipFree(p);

@@ -216,6 +216,7 @@ struct StreamArgs {
     const double* T;
     double* ifc_val;          // read; written for non-interface voxels by the write-back instantiation (Mode B)
     uint8_t* ifc_cnt;
+    const double* dep_val;    // plane L-1 deposition rates by temperature (SlabView::dep_val)
     double* rowsum;
     int32_t* rowcnt;
 };
@@ -281,8 +282,8 @@ __device__ __forceinline__ void sweep_row(const StreamArgs& A, const double* kta
                 if (empty) {
                     const double Traw = (h < 2) ? (h == 0 ? Ta.x : Ta.y) : (h == 2 ? Tb.x : Tb.y);
                     const double Tc = pymax(Traw, 1.0);
-                    if (top) {
-                        const double rate = A.nu_dep * exp(-(A.T_melt - Tc) / (A.kT * Tc));
+                    if (top) {          // nu_dep * exp(-(T_melt - T')/(kT T')), evaluated per sweep by k_interface's tail
+                        const double rate = A.dep_val[(int64_t)j * A.pitchT + k0 + h];
                         if (finite_d(rate)) { depv = rate; ++cdep; }
                     }
                     if (f & 0x0F00u) {                       // has W/Re/C neighbours: interface voxel
@@ -802,6 +803,16 @@ __device__ __forceinline__ void ifc_eval_atom(const KParams& P, const SlabView& 
     }
 }
 
+// deposition rates of plane L-1 as a function of temperature (every full sweep, by the interface kernels' threads)
+__device__ __forceinline__ void dep_fill(const KParams& P, const SlabView& S, int gtid, int nthreads)
+{
+    const int L = S.L, lp = L - 1 - S.gi0;
+    if (lp < 0 || lp >= S.nloc) return;
+    for (int idx = gtid; idx < L * L; idx += nthreads) {
+        const int j = idx / L, k = idx - j * L;
+        S.dep_val[(int64_t)j * S.pitchT + k] = dep_rate(P, pymax(S.T[S.tidx(lp + 2, j, k)], 1.0));
+    }
+}
 // every step: EMPTY/DIFF category sum + count of every listed voxel, one voxel per lane.
 // Latency-bound gather kernel: all loads of a phase are issued together (own fields + 14
 // neighbour states, then 7 neighbours' vectors / temperatures at a time from clamped-safe
@@ -828,6 +839,7 @@ __global__ __launch_bounds__(256) void k_interface(KParams P, SlabView S, const 
         S.ifc_val[t] = sum;
         S.ifc_cnt[t] = (uint8_t)cnt;
     }
+    dep_fill(P, S, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 // Same results for long lists (Mode B, where most of the lattice becomes interface): a block takes tiles of
@@ -879,6 +891,7 @@ __global__ __launch_bounds__(256) void k_interface_part(KParams P, SlabView S, c
             S.ifc_cnt[t] = (uint8_t)cnt;
         }
     }
+    dep_fill(P, S, blockIdx.x * 256 + tid, gridDim.x * 256);
 }
 
 // ---- apply -------------------------------------------------------------------------------

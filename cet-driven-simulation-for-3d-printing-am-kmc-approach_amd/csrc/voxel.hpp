@@ -65,6 +65,8 @@ struct SlabView {
     int32_t* rowcnt;
     // interface voxels (voxels owning attachment / diffusion events), see k_interface:
     double* ifc_val;    // [(nloc+4)][L][pitchT] EMPTY- or DIFF-category sum of an interface voxel (tidx)
+    double* dep_val;    // [L][pitchT] deposition rate of every (j,k) of plane L-1 from its T alone (kmc_event_rates.py:59-63;
+                        // emptiness is tested by the reader); refreshed by k_interface*; used iff the slab owns plane L-1
     uint8_t* ifc_cnt;   // same indexing: its event count
     uint8_t* ifc_in;    // same indexing: 1 if the voxel is in ifc_list
     uint32_t* ifc_code; // same indexing: packed neighbourhood of a listed voxel (ifc_encode), kept current by apply
