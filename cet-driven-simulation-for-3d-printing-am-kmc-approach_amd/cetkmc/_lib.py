@@ -58,6 +58,14 @@ class Counters(C.Structure):
                [(n, C.c_double) for n in ("ms_thermal", "ms_interface", "ms_sweep", "ms_dirty_rows", "ms_reduce", "ms_select_apply")]
 
 
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+
+
+class HostComm(C.Structure):
+    _fields_ = [("allgather", ALLGATHER_FN), ("exchange", EXCHANGE_FN), ("user", C.c_void_p)]
+
+
 class RunResult(C.Structure):
     _fields_ = [
         ("steps_done", C.c_int64), ("status", C.c_int32), ("np_used", C.c_int64), ("q_used", C.c_int64),
@@ -75,6 +83,7 @@ PROTOTYPES = {
     "cetkmc_create": (C.c_int, [_P(Params), C.c_int, C.c_int, _P(C.c_int), _P(C.c_void_p)]),
     "cetkmc_get_unique_id": (C.c_int, [C.c_char_p]),
     "cetkmc_create_rank": (C.c_int, [_P(Params), C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, _P(C.c_void_p)]),
+    "cetkmc_create_rank_host": (C.c_int, [_P(Params), C.c_int, C.c_int, C.c_int, C.c_int, _P(HostComm), _P(C.c_void_p)]),
     "cetkmc_destroy": (C.c_int, [C.c_void_p]),
     "cetkmc_set_params": (C.c_int, [C.c_void_p, _P(Params)]),
     "cetkmc_sync": (C.c_int, [C.c_void_p]),

@@ -59,7 +59,8 @@ class Engine:
     GPU (decomposition check); ``rank/nranks/unique_id`` selects the one-process-per-GPU
     RCCL mode."""
 
-    def __init__(self, L, impurity_c=0.0, params=None, n_slabs=1, device=0, rank=None, nranks=None, unique_id=None):
+    def __init__(self, L, impurity_c=0.0, params=None, n_slabs=1, device=0, rank=None, nranks=None, unique_id=None,
+                 host_comm=None):
         self.lib = _lib.load()
         self.L = int(L)
         self.params = params if params is not None else default_params(impurity_c)
@@ -70,6 +71,12 @@ class Engine:
         if rank is None:
             devs = (C.c_int * n_slabs)(*([device] * n_slabs))
             rc = self.lib.cetkmc_create(C.byref(self.params), self.L, n_slabs, devs, C.byref(self.h))
+        elif host_comm is not None:
+            # bring-up / test transport: collectives relayed through Python callables (see host_transport.py)
+            allgather, exchange = host_comm
+            self._hc = _lib.HostComm(_lib.ALLGATHER_FN(allgather), _lib.EXCHANGE_FN(exchange), None)     # keep alive
+            rc = self.lib.cetkmc_create_rank_host(C.byref(self.params), self.L, int(rank), int(nranks), int(device),
+                                                  C.byref(self._hc), C.byref(self.h))
         else:
             rc = self.lib.cetkmc_create_rank(C.byref(self.params), self.L, int(rank), int(nranks), int(device),
                                              unique_id, C.byref(self.h))

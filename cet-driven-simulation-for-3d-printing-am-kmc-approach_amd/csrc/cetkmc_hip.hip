@@ -137,6 +137,8 @@ struct Handle {
     int64_t cc_n_clusters = -1;
     std::vector<int> cc_roots_sorted;
     std::vector<hipEvent_t> prof;
+    cetkmc_host_comm hc{};       // host-relay transport (cetkmc_create_rank_host); used when comm is null
+    std::vector<char> hc_stage;
     cetkmc_counters cnt{};       // cetkmc_get_counters: work issued / bytes moved / per-phase device time
 };
 
@@ -453,6 +455,27 @@ StreamArgs stream_args(Handle* h, const SlabView& v)
     return sa;
 }
 
+// ---- collectives: RCCL on the stream, or relayed through host callbacks (bring-up / test transport) ------
+inline bool multi_rank(const Handle* h) { return h->comm != nullptr || h->hc.allgather != nullptr; }
+
+// in-place all-gather of `per` bytes per rank inside the device buffer `buf` (rank r's part at buf + r*per)
+int comm_allgather(Handle* h, void* buf, size_t per)
+{
+    if (h->comm) {
+        NCCLCHK(g_rccl.AllGather((const char*)buf + per * h->rank, buf, per, ncclChar, h->comm, h->stream));
+        return 0;
+    }
+    if (!h->hc.allgather) return 0;
+    h->hc_stage.resize(std::max(h->hc_stage.size(), per * h->nranks));
+    char* host = h->hc_stage.data();
+    HIPCHK(hipMemcpyAsync(host + per * h->rank, (const char*)buf + per * h->rank, per, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->hc.allgather(h->hc.user, host + per * h->rank, host, (int64_t)per)) return fail("host all-gather callback failed");
+    HIPCHK(hipMemcpyAsync(buf, host, per * h->nranks, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 // Incremental step (run_steps with incremental = 1, between temperature updates): only the rows the
 // previous event made stale are re-evaluated; their planes' block sums follow.
 int launch_dirty_rows(Handle* h, hipEvent_t ev_a, hipEvent_t ev_b)
@@ -467,10 +490,7 @@ int launch_dirty_rows(Handle* h, hipEvent_t ev_a, hipEvent_t ev_b)
         hipLaunchKernelGGL(k_plane_reduce_dirty, dim3(24 * 3), dim3(64), 0, h->stream, view_of(h, (int)s), h->d_blocks,
                            (const int*)h->d_dirty, (const StepState*)h->d_ss);
     HIPCHK(hipGetLastError());
-    if (h->comm) {
-        const size_t per = (size_t)3 * (h->L / h->nranks) * sizeof(BlockEnt);
-        NCCLCHK(g_rccl.AllGather((const char*)h->d_blocks + per * h->rank, h->d_blocks, per, ncclChar, h->comm, h->stream));
-    }
+    if (multi_rank(h)) CHK(comm_allgather(h, h->d_blocks, (size_t)3 * (h->L / h->nranks) * sizeof(BlockEnt)));
     h->swept = true;
     return 0;
 }
@@ -511,10 +531,7 @@ int launch_sweep(Handle* h, bool batch, hipEvent_t ev_a = nullptr, hipEvent_t ev
         hipLaunchKernelGGL(k_plane_reduce, dim3(3 * v.nloc), dim3(64), 0, h->stream, v, h->d_blocks, ss);
     }
     HIPCHK(hipGetLastError());
-    if (h->comm) {
-        const size_t per = (size_t)3 * (h->L / h->nranks) * sizeof(BlockEnt);
-        NCCLCHK(g_rccl.AllGather((const char*)h->d_blocks + per * h->rank, h->d_blocks, per, ncclChar, h->comm, h->stream));
-    }
+    if (multi_rank(h)) CHK(comm_allgather(h, h->d_blocks, (size_t)3 * (h->L / h->nranks) * sizeof(BlockEnt)));
     if (ev_post) HIPCHK(hipEventRecord(ev_post, h->stream));
     h->swept = true;
     return 0;
@@ -527,10 +544,7 @@ int launch_select(Handle* h, const BatchCfg& cfg, double r_direct, int info_only
                        (const double*)h->d_u_pick, r_direct, (const double*)h->d_ktab,
                        h->d_events_all + h->my_first, info_only, h->sweep_variant == 1 ? 1 : 0);
     HIPCHK(hipGetLastError());
-    if (h->comm && !info_only) {
-        NCCLCHK(g_rccl.AllGather((const char*)(h->d_events_all + h->rank), h->d_events_all, sizeof(cetkmc_event),
-                                 ncclChar, h->comm, h->stream));
-    }
+    if (multi_rank(h) && !info_only) CHK(comm_allgather(h, h->d_events_all, sizeof(cetkmc_event)));
     return 0;
 }
 
@@ -538,7 +552,7 @@ int launch_select(Handle* h, const BatchCfg& cfg, double r_direct, int info_only
 // across ranks
 int launch_select_apply(Handle* h, const BatchCfg& cfg, int eval_touched, int* dirty)
 {
-    if (!h->comm) {
+    if (!multi_rank(h)) {
         hipLaunchKernelGGL(k_select_apply, dim3(1), dim3(256), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
                            (int)h->slabs.size(), h->L, h->PB, (const BlockEnt*)h->d_blocks, h->d_ss, cfg,
                            (const double*)h->d_u_pick, (const double*)h->d_ktab, h->d_events_all + h->my_first,
@@ -580,6 +594,22 @@ int exchange_T_halo(Handle* h, int buf)
             NCCLCHK(g_rccl.Recv(T + plane * (s.v.nloc + 2), cnt, ncclChar, h->rank + 1, h->comm, h->stream));
         }
         NCCLCHK(g_rccl.GroupEnd());
+    } else if (h->hc.exchange && h->nranks > 1) {
+        Slab& s = h->slabs[0];
+        double* T = s.Tbuf[buf];
+        const size_t cnt = 2 * plane * 8;
+        h->hc_stage.resize(std::max(h->hc_stage.size(), 4 * cnt));
+        char* host = h->hc_stage.data();           // [send_lo | send_hi | recv_lo | recv_hi]
+        const bool lo = h->rank > 0, hi = h->rank < h->nranks - 1;
+        if (lo) HIPCHK(hipMemcpyAsync(host, T + plane * 2, cnt, hipMemcpyDeviceToHost, h->stream));
+        if (hi) HIPCHK(hipMemcpyAsync(host + cnt, T + plane * s.v.nloc, cnt, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->hc.exchange(h->hc.user, lo ? h->rank - 1 : -1, hi ? h->rank + 1 : -1, host, host + 2 * cnt, host + cnt, host + 3 * cnt,
+                           (int64_t)cnt))
+            return fail("host halo-exchange callback failed");
+        if (lo) HIPCHK(hipMemcpyAsync(T, host + 2 * cnt, cnt, hipMemcpyHostToDevice, h->stream));
+        if (hi) HIPCHK(hipMemcpyAsync(T + plane * (s.v.nloc + 2), host + 3 * cnt, cnt, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
     }
     return 0;
 }
@@ -721,6 +751,22 @@ int cetkmc_create_rank(const cetkmc_params* p, int L, int rank, int nranks, int 
             return fail(m);
         }
     }
+    return 0;
+}
+
+int cetkmc_create_rank_host(const cetkmc_params* p, int L, int rank, int nranks, int device_id, const cetkmc_host_comm* hc,
+                            void** handle)
+{
+    if (!hc || !hc->allgather || !hc->exchange) return fail("host transport callbacks required");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail("bad rank/nranks");
+    if (L % nranks != 0) return fail("L must be divisible by the number of ranks");
+    if (nranks > 1 && L / nranks < 2) return fail("each slab needs at least 2 planes");
+    const int n = L / nranks;
+    std::vector<std::pair<int, int>> ranges{{rank * n, n}};
+    CHK(create_common(p, L, ranges, device_id, nranks, rank, handle));
+    Handle* h = (Handle*)*handle;
+    h->rank = rank; h->nranks = nranks;
+    h->hc = *hc;
     return 0;
 }
 
@@ -1155,7 +1201,7 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
     if (!h || !a || !res) return fail("null argument");
     const int64_t n = a->n_steps;
     if (n < 0) return fail("n_steps < 0");
-    if (h->comm && h->nranks > 1) return fail("cetkmc_run_supersteps: single process only");
+    if (multi_rank(h) && h->nranks > 1) return fail("cetkmc_run_supersteps: single process only");
     if (h->sweep_variant != 1) return fail("cetkmc_run_supersteps needs sweep_variant 1");
     if (a->box < 8 || a->box > 16 || (a->box & 1) || h->L % a->box) return fail("box must be even, 8..16, and divide L");
     int64_t n_therm = 0;

@@ -162,6 +162,22 @@ int cetkmc_create(const cetkmc_params* p, int L, int n_slabs, const int* device_
 int cetkmc_get_unique_id(char out[128]);
 int cetkmc_create_rank(const cetkmc_params* p, int L, int rank, int nranks, int device_id,
                        const char unique_id[128], void** handle);
+/* Bring-up / test transport: the same per-rank device code path as cetkmc_create_rank, with the three collectives
+ * relayed through host callbacks (e.g. torch.distributed over gloo) instead of RCCL; the call synchronises the
+ * stream around every exchange, and several ranks may share one GPU.  Callbacks return 0 on success.
+ *   allgather(user, send, recv, nbytes): every rank contributes nbytes at `send`; recv gets nranks*nbytes in rank order
+ *   exchange (user, lo, hi, send_lo, recv_lo, send_hi, recv_hi, nbytes): swap nbytes with rank lo and with rank hi
+ *                                                                       (-1: no such neighbour)                    */
+typedef int (*cetkmc_allgather_fn)(void* user, const void* send, void* recv, int64_t nbytes);
+typedef int (*cetkmc_exchange_fn)(void* user, int lo, int hi, const void* send_lo, void* recv_lo, const void* send_hi,
+                                  void* recv_hi, int64_t nbytes);
+typedef struct cetkmc_host_comm {
+    cetkmc_allgather_fn allgather;
+    cetkmc_exchange_fn exchange;
+    void* user;
+} cetkmc_host_comm;
+int cetkmc_create_rank_host(const cetkmc_params* p, int L, int rank, int nranks, int device_id, const cetkmc_host_comm* hc,
+                            void** handle);
 int cetkmc_destroy(void* handle);
 int cetkmc_set_params(void* handle, const cetkmc_params* p);
 int cetkmc_sync(void* handle);

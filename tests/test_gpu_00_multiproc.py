@@ -1,0 +1,90 @@
+"""Real multi-process runs of the per-rank device code path on ONE GPU: 2 and 3 ranks share device 0, each owns an
+axis-0 slab (+2 halo planes), and the engine's three collectives (all-gather of block sums, all-gather of event
+records, temperature-halo exchange) travel through the host-relay transport over gloo instead of RCCL
+(cetkmc_create_rank_host).  Everything else -- kernels, owner selection, event application from the gathered
+record, RNG cursors -- is exactly what runs under the RCCL communicator.  Result: bit-identical to the single-process
+engine.  (First in collection order on purpose: the parent spawns its workers before anything initialises the GPU
+in this process.)"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _inputs(L, n, seed):
+    sys.path.insert(0, HERE)
+    from helpers import random_lattice
+    fields = random_lattice(L, seed, fill=0.25)
+    rs = np.random.RandomState(seed + 1)
+    return fields, (rs.random_sample(n), rs.random_sample(n), rs.random_sample(n * (L * L + 2)))
+
+
+def _run(eng, a0, a1, fields, streams, n, mode):
+    state, theta, phi, T, defects = fields
+    u_pick, u_def, u_np = streams
+    eng.upload_planes(a0, a1, state[a0:a1], theta[a0:a1], phi[a0:a1], T[a0:a1], defects[a0:a1])
+    kw = dict(rng_mode=0, thermal_mode=1, incremental=(mode == "incremental"))
+    if mode == "laser":
+        from cetkmc import synthetic
+        eng.set_prev_state(None)
+        kw = dict(rng_mode=1, seed=9, thermal_mode=2, q_planes=synthetic.laser_planes(eng.L, 0, n))
+    r = eng.run_steps(0, n, 0.05, u_pick, u_def, u_np, **kw)
+    assert r["done"] == n and r["status"] == 0, r
+    d = eng.download_planes(eng.i0, eng.i1, state=True, theta=True, phi=True, T=True, defects=True)
+    info = eng.rate_sweep()
+    return r, d, info
+
+
+def _worker(rank, world, port, L, n, seed, mode, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    root = os.path.dirname(HERE)
+    sys.path.insert(0, os.path.join(root, "cet-driven-simulation-for-3d-printing-am-kmc-approach_amd"))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cetkmc
+    from cetkmc import host_transport
+    fields, streams = _inputs(L, n, seed)
+    eng = cetkmc.Engine(L, impurity_c=0.2, device=0, rank=rank, nranks=world, host_comm=host_transport.torch_callbacks())
+    a0, a1 = max(0, eng.i0 - 2), min(L, eng.i1 + 2)
+    r, d, info = _run(eng, a0, a1, fields, streams, n, mode)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), totals=r["totals"], events=r["events"], n_events=r["n_events"],
+             np_used=r["np_used"], i0=eng.i0, i1=eng.i1, info=np.array(info, dtype=np.float64), **d)
+    eng.close()
+    dist.barrier()
+    if rank == 0:       # the single-process engine on the same inputs
+        ref = cetkmc.Engine(L, impurity_c=0.2)
+        r, d, info = _run(ref, 0, L, fields, streams, n, mode)
+        np.savez(os.path.join(out_dir, "ref.npz"), totals=r["totals"], events=r["events"], n_events=r["n_events"],
+                 np_used=r["np_used"], info=np.array(info, dtype=np.float64), **d)
+        ref.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,L,mode", [(2, 16, "full"), (3, 24, "full"), (2, 20, "incremental"), (2, 16, "laser")])
+def test_ranks_sharing_one_gpu_match_single_process(world, L, mode, tmp_path):
+    import torch.multiprocessing as mp
+    n = 70
+    mp.spawn(_worker, args=(world, _free_port(), L, n, 31, mode, str(tmp_path)), nprocs=world, join=True)
+    ref = np.load(tmp_path / "ref.npz")
+    for rank in range(world):
+        z = np.load(tmp_path / f"rank{rank}.npz")
+        # every rank logs the same totals / events / counts / stream position as the undivided run
+        assert np.array_equal(z["totals"], ref["totals"])
+        assert z["events"].tobytes() == ref["events"].tobytes()
+        assert np.array_equal(z["n_events"], ref["n_events"]) and z["np_used"] == ref["np_used"]
+        assert np.array_equal(z["info"], ref["info"])
+        i0, i1 = int(z["i0"]), int(z["i1"])
+        for k in ("state", "theta", "phi", "T", "defects"):
+            assert np.array_equal(z[k], ref[k][i0:i1]), (rank, k)
