@@ -496,7 +496,7 @@ int launch_dirty_rows(Handle* h, hipEvent_t ev_a, hipEvent_t ev_b)
 }
 
 int launch_sweep(Handle* h, bool batch, hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr, bool skip_ifc = false,
-                 bool write_vox = false, hipEvent_t ev_pre = nullptr, hipEvent_t ev_post = nullptr)
+                 bool write_vox = false, hipEvent_t ev_pre = nullptr, hipEvent_t ev_post = nullptr, int wv_box = 0, int wv_sector = 0)
 {
     ++h->cnt.sweeps;
     for (auto& sl : h->slabs) h->cnt.alg_bytes_sweep += (int64_t)10 * sl.v.nloc * h->L * h->L;   // cls u16 + T f64 per voxel
@@ -510,7 +510,8 @@ int launch_sweep(Handle* h, bool batch, hipEvent_t ev_a = nullptr, hipEvent_t ev
     for (size_t s = 0; s < h->slabs.size(); ++s) {
         SlabView v = view_of(h, (int)s);
         if (h->sweep_variant == 1) {
-            const StreamArgs sa = stream_args(h, v);
+            StreamArgs sa = stream_args(h, v);
+            sa.wv_box = wv_box; sa.wv_sector = wv_sector;
             const int nib = sa.group_count;
             const dim3 g8(nib * ((h->L + 7) / 8)), g4(nib * ((h->L + 3) / 4));
             if (h->stream_tj == 8 && !write_vox)
@@ -1194,6 +1195,18 @@ int cetkmc_get_counters(void* handle, cetkmc_counters* out, int reset)
 }
 
 // ---- Mode B: synchronous super-steps over spatial boxes (superstep.hpp) ------------------------------
+// interface list of every slab rebuilt from the membership flags, in address order
+int relist(Handle* h)
+{
+    for (size_t sl = 0; sl < h->slabs.size(); ++sl) {
+        SlabView v = view_of(h, (int)sl);
+        HIPCHK(hipMemsetAsync(v.ifc_n, 0, sizeof(int), h->stream));
+        hipLaunchKernelGGL(k_ifc_relist, dim3((v.nloc * h->L + RELIST_ROWS - 1) / RELIST_ROWS), dim3(256), 0, h->stream, v, (const StepState*)nullptr);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_result* res, double* totals,
                           cetkmc_event* events, int64_t* n_executed)
 {
@@ -1251,26 +1264,28 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
     int64_t q_idx = 0;
     for (int64_t s = 0; s < n; ++s) {
         const int64_t g = a->step0 + s;
-        if (a->thermal_mode && g % 20 == 0) {
+        const bool therm = a->thermal_mode && g % 20 == 0;
+        if (therm) {
             if (a->thermal_mode == 1) CHK(launch_thermal(h, a->thermal_dt, 0, nullptr, 0, 1, true));
             else { CHK(launch_thermal(h, a->thermal_dt, 1, h->d_q + (size_t)q_idx * L2, a->use_latent, 1, true)); ++q_idx; }
         }
-        CHK(launch_sweep(h, true, nullptr, nullptr, false, true));   // + per-voxel sums written back (all voxels)
-        CHK(launch_select(h, cfg, 0.0, 1));                          // total, counts, termination test
+        // interface sums: the list kernel after a temperature update / at the start of the batch (list rebuilt in
+        // address order first); otherwise they are current -- k_domain_touch re-evaluated what the events changed
+        const bool need_ifc = (s == 0) || therm;
+        if (need_ifc && s > 0) CHK(relist(h));
+        // + per-voxel sums written back for the voxels this super-step's picks read (the active octants)
+        CHK(launch_sweep(h, true, nullptr, nullptr, !need_ifc, true, nullptr, nullptr, C.box, (int)(g & 7)));
+        CHK(launch_select(h, cfg, 0.0, 1));                              // total, counts, termination test
         hipLaunchKernelGGL(k_domain_pick, dim3(D), dim3(64), shmem, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
                            (int)h->slabs.size(), h->L, C, (const StepState*)h->d_ss, d_picks);
         hipLaunchKernelGGL(k_domain_slot_apply, dim3((D + 63) / 64), dim3(64), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
                            (int)h->slabs.size(), h->L, D, C, h->d_ss, (const DomPick*)d_picks, (const double*)h->d_ktab, d_dom, d_cnt, d_log);
-        hipLaunchKernelGGL(k_domain_touch, dim3((D + 7) / 8), dim3(256), 0, h->stream, (const SlabView*)h->d_views[h->cur],
-                           (int)h->slabs.size(), D, (const cetkmc_event*)d_dom, (const StepState*)h->d_ss);
-        for (size_t sl = 0; sl < h->slabs.size(); ++sl) {
-            SlabView v = view_of(h, (int)sl);
-            HIPCHK(hipMemsetAsync(v.ifc_n, 0, sizeof(int), h->stream));
-            hipLaunchKernelGGL(k_ifc_relist, dim3((v.nloc * h->L + RELIST_ROWS - 1) / RELIST_ROWS), dim3(256), 0, h->stream, v, (const StepState*)nullptr);
-        }
+        hipLaunchKernelGGL(k_domain_touch, dim3((D + 7) / 8), dim3(256), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
+                           (int)h->slabs.size(), D, (const cetkmc_event*)d_dom, (const StepState*)h->d_ss, (const double*)h->d_ktab);
         hipLaunchKernelGGL(k_super_commit, dim3(1), dim3(1), 0, h->stream, h->d_ss, d_cnt, h->d_log_total, h->d_log_nev);
         h->swept = false;
     }
+    if (n > 0) CHK(relist(h));        // leave a complete, address-ordered interface list behind (Mode A reads it)
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipMemcpyAsync(&ss, h->d_ss, sizeof ss, hipMemcpyDeviceToHost, h->stream));

@@ -212,6 +212,7 @@ constexpr int STREAM_MAXCH = 4;   // chunks of 256 voxels per row (L <= 1024)
 struct StreamArgs {
     double T_melt, delta_T_c, kT, I0, rate_threshold, nu_dep;
     int L, gi0, nloc, RJ, pitchC, pitchT, Pk, group_first, group_count;
+    int wv_box, wv_sector;    // write-back instantiation: only voxels of the boxes' active octant are stored (wv_box 0: all)
     const uint16_t* cls;
     const double* T;
     double* ifc_val;          // read; written for non-interface voxels by the write-back instantiation (Mode B)
@@ -235,6 +236,11 @@ __device__ __forceinline__ void sweep_row(const StreamArgs& A, const double* kta
 {
     const int L = A.L;
     int cdep = 0, cdiff = 0, cemp = 0;
+    // Mode B write-back: is (plane, row) / is column k inside the active octant of its box?
+    const int wv_h = A.wv_box >> 1;
+    const bool wv_row = !WV || !A.wv_box ||
+        ((((A.gi0 + lp) % A.wv_box) >= wv_h) == (((A.wv_sector >> 2) & 1) != 0) && ((j % A.wv_box) >= wv_h) == (((A.wv_sector >> 1) & 1) != 0));
+    auto wv_k = [&](int k) { return ((k % A.wv_box) >= wv_h) == ((A.wv_sector & 1) != 0); };
 #pragma unroll 1
     for (int m = 0; m < nch; ++m) {
         const int k0 = (m << 8) + 4 * lane;
@@ -308,7 +314,7 @@ __device__ __forceinline__ void sweep_row(const StreamArgs& A, const double* kta
                     // 16-byte + one 2-byte store per voxel pair
                     const double wv = empty ? ev : dv;
                     if (!(h & 1)) { pw = wv; pc = wc; }
-                    else if (k0 + h - 1 < L) {
+                    else if (k0 + h - 1 < L && wv_row && (!A.wv_box || wv_k(k0 + h - 1) || wv_k(k0 + h))) {
                         *reinterpret_cast<double2*>(A.ifc_val + trow + h - 1) = make_double2(pw, wv);
                         *reinterpret_cast<uint16_t*>(A.ifc_cnt + trow + h - 1) = (uint16_t)(pc | (wc << 8));
                     }

@@ -164,14 +164,21 @@ __global__ __launch_bounds__(64) void k_domain_slot_apply(KParams P, const SlabV
 }
 
 // Interface upkeep for the touched voxels, after ALL lattice writes of the super-step.  8 boxes per 256-thread
-// block, 32 lanes per event (0..14 neighbourhood of the site, 16..30 of a diffusion target).  Only the
-// membership flag and the packed neighbourhood word are updated here; the list itself is rebuilt in address
-// order by k_ifc_relist (Mode B lists are long, and k_interface is bound by the locality of its gathers).
-__global__ __launch_bounds__(256) void k_domain_touch(const SlabView* __restrict__ slabs, int nslabs, int D,
-                                                      const cetkmc_event* __restrict__ dom_events, const StepState* __restrict__ ss)
+// block, 32 lanes per event (0..14 neighbourhood of the site, 16..30 of a diffusion target): membership flag,
+// packed neighbourhood word, and the voxel's EMPTY/DIFF category sum re-evaluated from that word exactly as
+// k_interface does.  These are the only listed voxels whose sums an event can change while T stands still, so the
+// interface kernel itself runs only on super-steps that follow a temperature update (and on the first of a
+// batch); the list is rebuilt in address order by k_ifc_relist right before it (k_interface is bound by the
+// locality of its gathers, Mode B lists are long).
+__global__ __launch_bounds__(256) void k_domain_touch(KParams P, const SlabView* __restrict__ slabs, int nslabs, int D,
+                                                      const cetkmc_event* __restrict__ dom_events, const StepState* __restrict__ ss,
+                                                      const double* __restrict__ ktab_g)
 {
+    __shared__ double ktab[225];
     if (ss->status) return;
     const int tid = threadIdx.x;
+    if (tid < 225) ktab[tid] = ktab_g[tid];
+    __syncthreads();
     const int d = blockIdx.x * 8 + (tid >> 5), l = tid & 31;
     if (d >= D || l == 15 || l == 31) return;
     const cetkmc_event ev = dom_events[d];
@@ -188,7 +195,16 @@ __global__ __launch_bounds__(256) void k_domain_touch(const SlabView* __restrict
         const unsigned code = ifc_encode(S, lp + 2, aj, ak, &hit);
         const int64_t t = S.tidx(lp + 2, aj, ak);
         if (hit) S.ifc_in[t] = 1;
-        if (hit || S.ifc_in[t]) S.ifc_code[t] = code;
+        if (!hit && !S.ifc_in[t]) continue;
+        S.ifc_code[t] = code;
+        const int st = (code >> 30) ? 4 : (int)((code >> 28) & 3u);
+        const double Tc = pymax(S.T[t], 1.0);
+        double sum = 0.0;
+        int cnt = 0;
+        if (st == 0) ifc_eval_empty(P, S, ktab, lp, aj, ak, t, code, Tc, sum, cnt);
+        else if (st != 4) ifc_eval_atom(P, S, lp, aj, ak, t, code, st, Tc, sum, cnt);
+        S.ifc_val[t] = sum;
+        S.ifc_cnt[t] = (uint8_t)cnt;
     }
 }
 
