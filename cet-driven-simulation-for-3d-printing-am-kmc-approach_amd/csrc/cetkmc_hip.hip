@@ -304,6 +304,18 @@ int create_common(const cetkmc_params* p, int L, const std::vector<std::pair<int
 
 SlabView view_of(Handle* h, int s) { SlabView v = h->slabs[s].v; v.T = h->slabs[s].Tbuf[h->cur]; return v; }
 
+// per-call device allocation released on every return path
+template <class T>
+struct DevTmp {
+    T* p = nullptr;
+    DevTmp() = default;
+    DevTmp(const DevTmp&) = delete;
+    DevTmp& operator=(const DevTmp&) = delete;
+    ~DevTmp() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc((void**)&p, n * sizeof(T)); }
+    operator T*() const { return p; }
+};
+
 // extended (owned + halo, clipped) global plane range of a slab
 void ext_range(const Handle* h, const Slab& s, int* a, int* b)
 {
@@ -998,21 +1010,19 @@ int cetkmc_enumerate_events(void* handle, cetkmc_event* buf, int64_t cap, int64_
     *n = total;
     if (!buf || cap <= 0 || total == 0) return 0;
     const int64_t m = std::min<int64_t>(cap, total);
-    cetkmc_event* d_out = nullptr;
-    HIPCHK(hipMalloc((void**)&d_out, (size_t)m * sizeof(cetkmc_event)));
+    DevTmp<cetkmc_event> d_out;
+    HIPCHK(d_out.alloc((size_t)m));
     for (size_t s = 0; s < h->slabs.size(); ++s) {
         const size_t rows = offs[s].size();
-        int64_t* d_off = nullptr;
-        HIPCHK(hipMalloc((void**)&d_off, rows * sizeof(int64_t)));
+        DevTmp<int64_t> d_off;
+        HIPCHK(d_off.alloc(rows));
         HIPCHK(hipMemcpyAsync(d_off, offs[s].data(), rows * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
         hipLaunchKernelGGL(k_enumerate, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, h->stream, h->kp, view_of(h, (int)s),
-                           (const double*)h->d_ktab, (const int64_t*)d_off, d_out, m);
+                           (const double*)h->d_ktab, (const int64_t*)d_off.p, d_out.p, m);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(h->stream));
-        HIPCHK(hipFree(d_off));
     }
     HIPCHK(hipMemcpy(buf, d_out, (size_t)m * sizeof(cetkmc_event), hipMemcpyDeviceToHost));
-    HIPCHK(hipFree(d_out));
     int64_t rank = 0;
     for (int64_t e = 0; e < m; ++e) if (buf[e].type == CETKMC_DEP) buf[e].dep_rank = rank++;
     return 0;
@@ -1240,10 +1250,15 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
         h->cap_steps = std::min({c1, c2, c3, c4, c5});
         if (a->thermal_mode == 2) CHK(grow(&h->d_q, &h->cap_q, (size_t)std::max<int64_t>(n_therm, 1) * L2));
     }
-    cetkmc_event* d_dom = nullptr;
-    DomPick* d_picks = nullptr;
-    unsigned long long* d_cnt = nullptr;
-    cetkmc_event* d_log = nullptr;
+    // per-call device buffers, released on every return path
+    struct Tmp {
+        cetkmc_event* dom = nullptr; DomPick* picks = nullptr; unsigned long long* cnt = nullptr; cetkmc_event* log = nullptr;
+        ~Tmp() { (void)hipFree(dom); (void)hipFree(picks); (void)hipFree(cnt); (void)hipFree(log); }
+    } tmp;
+    cetkmc_event*& d_dom = tmp.dom;
+    DomPick*& d_picks = tmp.picks;
+    unsigned long long*& d_cnt = tmp.cnt;
+    cetkmc_event*& d_log = tmp.log;
     HIPCHK(hipMalloc((void**)&d_dom, (size_t)D * sizeof(cetkmc_event)));
     HIPCHK(hipMalloc((void**)&d_picks, (size_t)D * sizeof(DomPick)));
     HIPCHK(hipMalloc((void**)&d_cnt, 2 * sizeof(unsigned long long)));
@@ -1301,7 +1316,6 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
     if (totals && ss.status == 1 && done < n) totals[done] = ss.total;
     if (n_executed && done > 0) HIPCHK(hipMemcpy(n_executed, h->d_log_nev, (size_t)done * 8, hipMemcpyDeviceToHost));
     if (events && done > 0) HIPCHK(hipMemcpy(events, d_log, (size_t)done * D * sizeof(cetkmc_event), hipMemcpyDeviceToHost));
-    (void)hipFree(d_dom); (void)hipFree(d_picks); (void)hipFree(d_cnt); (void)hipFree(d_log);
     return 0;
 }
 
@@ -1383,16 +1397,15 @@ int cetkmc_species_counts(void* handle, int64_t counts[6])
     Handle* h = (Handle*)handle;
     if (!h || !counts) return fail("null argument");
     HIPCHK(hipSetDevice(h->dev));
-    unsigned long long* d = nullptr;
-    HIPCHK(hipMalloc((void**)&d, 6 * sizeof(unsigned long long)));
+    DevTmp<unsigned long long> d;
+    HIPCHK(d.alloc(6));
     HIPCHK(hipMemsetAsync(d, 0, 6 * sizeof(unsigned long long), h->stream));
     for (size_t s = 0; s < h->slabs.size(); ++s)
-        hipLaunchKernelGGL(k_species_counts, dim3(1024), dim3(256), 0, h->stream, view_of(h, (int)s), d);
+        hipLaunchKernelGGL(k_species_counts, dim3(1024), dim3(256), 0, h->stream, view_of(h, (int)s), d.p);
     HIPCHK(hipGetLastError());
     unsigned long long out[6];
     HIPCHK(hipMemcpyAsync(out, d, sizeof out, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipFree(d));
     for (int c = 0; c < 6; ++c) counts[c] = (int64_t)out[c];
     return 0;
 }
@@ -1402,17 +1415,17 @@ int cetkmc_gather_species(void* handle, int species, int64_t* lin_idx, double* T
     Handle* h = (Handle*)handle;
     if (!h || !n) return fail("null argument");
     HIPCHK(hipSetDevice(h->dev));
-    unsigned long long* d_n = nullptr;
-    long long* d_idx = nullptr;
-    double* d_T = nullptr;
+    DevTmp<unsigned long long> d_n;
+    DevTmp<long long> d_idx;
+    DevTmp<double> d_T;
     const size_t c = (size_t)std::max<int64_t>(cap, 1);
-    HIPCHK(hipMalloc((void**)&d_n, sizeof(unsigned long long)));
-    HIPCHK(hipMalloc((void**)&d_idx, c * sizeof(long long)));
-    HIPCHK(hipMalloc((void**)&d_T, c * sizeof(double)));
+    HIPCHK(d_n.alloc(1));
+    HIPCHK(d_idx.alloc(c));
+    HIPCHK(d_T.alloc(c));
     HIPCHK(hipMemsetAsync(d_n, 0, sizeof(unsigned long long), h->stream));
     for (size_t s = 0; s < h->slabs.size(); ++s)
-        hipLaunchKernelGGL(k_gather_species, dim3(1024), dim3(256), 0, h->stream, view_of(h, (int)s), species, d_idx, d_T,
-                           (unsigned long long)(lin_idx && T_vals ? cap : 0), d_n);
+        hipLaunchKernelGGL(k_gather_species, dim3(1024), dim3(256), 0, h->stream, view_of(h, (int)s), species, d_idx.p, d_T.p,
+                           (unsigned long long)(lin_idx && T_vals ? cap : 0), d_n.p);
     HIPCHK(hipGetLastError());
     unsigned long long cnt = 0;
     HIPCHK(hipMemcpyAsync(&cnt, d_n, sizeof cnt, hipMemcpyDeviceToHost, h->stream));
@@ -1423,7 +1436,6 @@ int cetkmc_gather_species(void* handle, int species, int64_t* lin_idx, double* T
         HIPCHK(hipMemcpy(lin_idx, d_idx, m * sizeof(long long), hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(T_vals, d_T, m * sizeof(double), hipMemcpyDeviceToHost));
     }
-    HIPCHK(hipFree(d_n)); HIPCHK(hipFree(d_idx)); HIPCHK(hipFree(d_T));
     return 0;
 }
 
@@ -1432,19 +1444,18 @@ int cetkmc_set_defects_sparse(void* handle, const int64_t* lin_idx, int64_t n)
     Handle* h = (Handle*)handle;
     if (!h || (n > 0 && !lin_idx)) return fail("null argument");
     HIPCHK(hipSetDevice(h->dev));
-    long long* d_idx = nullptr;
+    DevTmp<long long> d_idx;
     if (n > 0) {
-        HIPCHK(hipMalloc((void**)&d_idx, (size_t)n * sizeof(long long)));
+        HIPCHK(d_idx.alloc((size_t)n));
         HIPCHK(hipMemcpyAsync(d_idx, lin_idx, (size_t)n * sizeof(long long), hipMemcpyHostToDevice, h->stream));
     }
     for (auto& s : h->slabs) {
         HIPCHK(hipMemsetAsync(s.v.defects, 0, s.nS, h->stream));
         if (n > 0) hipLaunchKernelGGL(k_scatter_defects, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0,
-                                      h->stream, s.v, (const long long*)d_idx, (long long)n);
+                                      h->stream, s.v, (const long long*)d_idx.p, (long long)n);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
-    if (d_idx) HIPCHK(hipFree(d_idx));
     h->swept = false;
     return 0;
 }
