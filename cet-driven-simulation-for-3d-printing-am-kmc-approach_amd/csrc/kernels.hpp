@@ -479,16 +479,46 @@ __global__ __launch_bounds__(64) void k_plane_reduce(SlabView S, BlockEnt* __res
 }
 
 // ---- LDS heap tree helpers (leaves at [P,2P), node n has children 2n, 2n+1) -------------
+// Built with two barriers instead of log2(P): every thread folds its P/256 consecutive leaves, the next six levels
+// are wave shuffles (a + b and b + a are the same double, so both lanes of a pair hold the node's value), thread 0
+// finishes the top two.  Same pairwise association as the level-by-level loop.  Callers sync before (leaves written).
 __device__ __forceinline__ void heap_build(double* hs, int* hf, int P, int tid)
 {
-    for (int n = P >> 1; n >= 1; n >>= 1) {
-        for (int idx = tid; idx < n; idx += 256) {
-            int node = n + idx;
+    if (P < 256) {
+        for (int n = P >> 1; n >= 1; n >>= 1) {
+            for (int idx = tid; idx < n; idx += 256) {
+                int node = n + idx;
+                hs[node] = hs[2 * node] + hs[2 * node + 1];
+                hf[node] = hf[2 * node] | hf[2 * node + 1];
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    for (int w = P >> 9, base = P >> 1; w >= 1; w >>= 1, base >>= 1)      // levels inside the thread's own leaves
+        for (int q = 0; q < w; ++q) {
+            const int node = base + w * tid + q;
             hs[node] = hs[2 * node] + hs[2 * node + 1];
             hf[node] = hf[2 * node] | hf[2 * node + 1];
         }
-        __syncthreads();
+    double v = hs[256 + tid];
+    int f = hf[256 + tid];
+#pragma unroll
+    for (int l = 0; l < 6; ++l) {
+        v = v + __shfl_xor(v, 1 << l);
+        f |= __shfl_xor(f, 1 << l);
+        if ((tid & ((2 << l) - 1)) == 0) {
+            const int node = (256 >> (l + 1)) + (tid >> (l + 1));
+            hs[node] = v; hf[node] = f;
+        }
     }
+    __syncthreads();
+    if (tid == 0) {
+        hs[2] = hs[4] + hs[5]; hf[2] = hf[4] | hf[5];
+        hs[3] = hs[6] + hs[7]; hf[3] = hf[6] | hf[7];
+        hs[1] = hs[2] + hs[3]; hf[1] = hf[2] | hf[3];
+    }
+    __syncthreads();
 }
 // go left iff the right half holds no events, or the left holds events and base+sum(left) >= r
 __device__ __forceinline__ int heap_descend(const double* hs, const int* hf, int P, double& base, double r)
@@ -526,13 +556,14 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
         hs[PB + idx] = v; hf[PB + idx] = f;
     }
     if (tid < 225) ktab[tid] = ktab_g[tid];
-    red[tid] = csum;
+#pragma unroll
+    for (int l = 0; l < 6; ++l) csum += __shfl_xor(csum, 1 << l);       // per-wave event count
+    if ((tid & 63) == 0) red[tid >> 6] = csum;
     __syncthreads();
-    for (int o = 128; o >= 1; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
     heap_build(hs, hf, PB, tid);
     if (tid == 0) {
         const double total = hs[1];
-        const long long n_events = red[0];
+        const long long n_events = red[0] + red[1] + red[2] + red[3];
         const long long n_dep = blocks[3 * (L - 1) + CAT_DEP].cnt;
         ss->total = total; ss->n_events = n_events; ss->n_dep = n_dep;
         int go = info_only ? 0 : 1;
