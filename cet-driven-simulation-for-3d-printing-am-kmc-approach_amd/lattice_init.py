@@ -64,14 +64,11 @@ def visualize_initial_seeds(state, atom_type, title="Initial Nucleation Sites", 
         ii, jj, kk = np.where(state == species)
         if ii.size:
             ax.scatter(kk, jj, ii, c=colour, label=label, alpha=0.6, s=10)
-    ax.set_xlabel("X")
-    ax.set_ylabel("Y")
-    ax.set_zlabel("Z (Build Direction)")
-    plt.title(title)
-    plt.legend()
-    plt.tight_layout()
-    plt.savefig(filename, dpi=150)
-    plt.close()
+    ax.set(xlabel="X", ylabel="Y", zlabel="Z (Build Direction)", title=title)
+    ax.legend()
+    fig.tight_layout()
+    fig.savefig(filename, dpi=150)
+    plt.close(fig)
 
 
 def save_lattice(state, orientation_theta, orientation_phi, T, atom_type, prefix="init"):

@@ -115,11 +115,16 @@ def calculate_G_over_R(G, R):
 
 
 def determine_CET(aspect_ratio, G_over_R, gr_threshold=CET_GR_THRESHOLD, ar_threshold=CET_AR_THRESHOLD):
-    if G_over_R is None or np.isinf(G_over_R):
+    """Columnar iff the aspect ratio (and, when a finite G/R is known, G/R as well) reaches its threshold; prints the
+    reference's debug line (utils.py:168-176)."""
+    elongated = aspect_ratio >= ar_threshold
+    have_gr = G_over_R is not None and not np.isinf(G_over_R)
+    if have_gr:
+        print(f"Debug: G_over_R={G_over_R:.2e}, AspectRatio={aspect_ratio:.2f}, thresholds={gr_threshold}/{ar_threshold}")
+        elongated = elongated and G_over_R >= gr_threshold
+    else:
         print(f"Debug: G_over_R invalid, using AspectRatio={aspect_ratio:.2f} vs threshold={ar_threshold}")
-        return "Columnar" if aspect_ratio >= ar_threshold else "Equiaxed"
-    print(f"Debug: G_over_R={G_over_R:.2e}, AspectRatio={aspect_ratio:.2f}, thresholds={gr_threshold}/{ar_threshold}")
-    return "Columnar" if (G_over_R >= gr_threshold and aspect_ratio >= ar_threshold) else "Equiaxed"
+    return "Columnar" if elongated else "Equiaxed"
 
 
 def validate_aspect_ratio(aspect_ratio, ar_threshold=CET_AR_THRESHOLD):
