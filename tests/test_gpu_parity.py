@@ -405,12 +405,13 @@ def test_thermal_kernel_variants_identical(L, n_slabs):
         assert np.array_equal(x, y)
 
 
-def test_large_L_two_chunks_per_row():
+@pytest.mark.parametrize("L", [264, 344])
+def test_large_L_two_chunks_per_row(L):
     """L > 256: rows span two 256-voxel chunks in the streaming kernel (the N=2/4/8 bench sizes 320/408/512
-    take this path).  Streaming == simple kernel bit for bit, slab-count invariant, incl. after stepping."""
+    take this path); L = 344 additionally needs the 2048-leaf block heap of the selection (3L > 1024, as at
+    408 and 512).  Streaming == simple kernel bit for bit, slab-count invariant, incl. after stepping."""
     import cetkmc
     from cetkmc import synthetic
-    L = 264
     st, th, ph, T, df = synthetic.planes(L, 0, L, seed=3)
     rs = np.random.RandomState(9)
     # sprinkle isolated atoms / defects into the empty region so every event family occurs there too
@@ -548,3 +549,31 @@ def test_counters_and_phase_profile():
         outs.append((r["totals"].tobytes(), r["events"].tobytes(), e.download()["theta"].tobytes()))
         e.close()
     assert outs[0] == outs[1] == outs[2]
+
+
+def test_selection_with_2048_leaf_block_heap_vs_oracle(oracle_mod):
+    """3L > 1024 (here L = 344; the 4- and 8-GPU bench sizes 408 and 512 as well): the selection kernel's block
+    heap has 2048 leaves, 8 per thread.  Chosen events, totals and counts of a few steps equal the oracle's."""
+    import cetkmc
+    from cetkmc import synthetic
+    L, n = 344, 3
+    st, th, ph, T, df = synthetic.planes(L, 0, L, seed=11)
+    rs = np.random.RandomState(4)
+    u_pick, u_def, u_np = rs.random_sample(n), rs.random_sample(n), rs.random_sample(2 * n + 2)
+    q = synthetic.laser_planes(L, 0, n)
+    e = cetkmc.Engine(L, impurity_c=0.2)
+    e.upload_planes(0, L, st, th, ph, T, df)
+    e.set_prev_state(None)
+    rg = e.run_steps(0, n, 3e-3, u_pick, u_def, u_np, rng_mode=1, seed=5, thermal_mode=2, q_planes=q)
+    e.close()
+    oracle_mod.set_threads(min(16, os.cpu_count() or 1))
+    try:
+        lat = oracle_mod.Lattice(st.astype(np.int64), th, ph, T, df.astype(np.int64), impurity_c=0.2)
+        ro = lat.run_steps(0, n, 3e-3, u_pick, u_def, u_np, rng_mode=1, seed=5, thermal_mode=2, q_planes=q)
+    finally:
+        oracle_mod.set_threads(1)
+    assert rg["done"] == ro["done"] == n
+    for f in ("type", "pos", "target", "atom"):
+        assert np.array_equal(rg["events"][f], ro["events"][f]), f
+    assert np.array_equal(rg["n_events"], ro["n_events"])
+    assert relerr(rg["totals"], ro["totals"]).max() <= RATE_RTOL
