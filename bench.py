@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--no-incremental", action="store_true", help="skip the extra exact-incremental-mode run")
     ap.add_argument("--no-mode-b", action="store_true", help="skip the extra Mode B (super-step) run")
     ap.add_argument("--no-phases", action="store_true", help="skip the extra per-phase timing run")
+    ap.add_argument("--set-option", action="append", default=[], metavar="KEY=INT", help="cetkmc_set_option before the run")
     ap.add_argument("--overlap-interface", type=int, default=-1,
                     help="speculative interface evaluation of the next step during select/collectives: 1 on, 0 off (default: engine default = off)")
     ap.add_argument("--extras-multi", action="store_true",
@@ -142,6 +143,9 @@ def main():
 
     if a.overlap_interface >= 0:
         eng.set_option("overlap_interface", a.overlap_interface)
+    for kv in a.set_option:                       # engine options for A/B runs, e.g. --set-option fused_reduce=0
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
 
     # ---- synthetic input, resident in HBM before anything is timed -----------------------
     a0, a1 = max(0, eng.i0 - 2), min(L, eng.i1 + 2)
