@@ -577,3 +577,31 @@ def test_selection_with_2048_leaf_block_heap_vs_oracle(oracle_mod):
         assert np.array_equal(rg["events"][f], ro["events"][f]), f
     assert np.array_equal(rg["n_events"], ro["n_events"])
     assert relerr(rg["totals"], ro["totals"]).max() <= RATE_RTOL
+
+
+@pytest.mark.parametrize("incremental", [False, True])
+def test_long_run_vs_oracle(oracle_mod, incremental):
+    """3000 steps (15 defect-mask refreshes, 150 temperature updates, the interface list growing all the way) through
+    the batched protocol: every chosen event, count and total, the stream positions and the final fields equal the
+    oracle's."""
+    z = dict(L=18, n_steps=3000, temp=2800.0, defect_fraction=0.01, n_seeds=12, impurity_c=0.15)
+
+    class _Gpu(_GpuBatched):
+        def run_steps(self, *a, **k):
+            return self.e.run_steps(*a, incremental=incremental, **k)
+
+    oracle_mod.set_threads(min(8, os.cpu_count() or 1))
+    try:
+        g, tg, lg = _drive_batched(lambda *a: _Gpu(*a), z, rng_mode=0, batch=190)
+        o, to, lo = _drive_batched(lambda *a: _OracleBatched(oracle_mod, *a), z, rng_mode=0, batch=190)
+    finally:
+        oracle_mod.set_threads(1)
+    assert len(lg) == len(lo)
+    for rg, ro in zip(lg, lo):
+        for f in ("type", "pos", "target", "atom", "dep_rank"):
+            assert np.array_equal(rg["events"][f], ro["events"][f]), f
+        assert np.array_equal(rg["n_events"], ro["n_events"]) and rg["np_used"] == ro["np_used"]
+        assert relerr(rg["totals"], ro["totals"]).max() <= RATE_RTOL
+    for a, b in zip(g.final(), o.final()):
+        assert np.array_equal(a, b)
+    assert tg == to
