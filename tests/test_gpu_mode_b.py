@@ -87,19 +87,31 @@ def test_supersteps_argument_errors():
     e.close()
 
 
-def test_supersteps_full_size_properties():
+def test_supersteps_full_size_properties(oracle_mod):
     """256^3, box 8 (32768 boxes): executed events = non-idle boxes, every event inside its window, written
-    voxels pairwise distinct, species histogram moves by exactly the executed events."""
+    voxels pairwise distinct, species histogram moves by exactly the executed events; the first two super-steps'
+    per-box events equal the CPU comparator's."""
+    import os
+
     import cetkmc
     from cetkmc import synthetic
     L, box, n = 256, 8, 6
     st, th, ph, T, df = synthetic.planes(L, 0, L, seed=42)
+    oracle_mod.set_threads(min(16, os.cpu_count() or 1))
+    try:
+        lat = oracle_mod.Lattice(st.astype(np.int64), th, ph, T, df.astype(np.int64), impurity_c=0.2)
+        ro = lat.run_supersteps(0, 2, box, 3e-3, 42, thermal_mode=2, q_planes=synthetic.laser_planes(L, 0, 2))
+    finally:
+        oracle_mod.set_threads(1)
+    del lat
     e = cetkmc.Engine(L, impurity_c=0.2)
     e.upload_planes(0, L, st, th, ph, T, df)
     e.set_prev_state(None)
     c0 = e.species_counts()
     r = e.run_supersteps(0, n, box, 3e-3, seed=42, thermal_mode=2, q_planes=synthetic.laser_planes(L, 0, n), want_events=True)
     assert r["done"] == n and r["domains"] == 32 ** 3
+    for f in ("type", "pos", "target", "atom"):
+        assert np.array_equal(r["events"][f][:2], ro["events"][f]), f
     nb, H = L // box, box // 2
     for s in range(n):
         ev = r["events"][s]
@@ -117,3 +129,34 @@ def test_supersteps_full_size_properties():
     filled = sum(int((r["events"][s]["type"][r["events"][s]["type"] >= 0] != 1).sum()) for s in range(n))
     assert c0[0] - c1[0] == filled          # every dep/nuc/att event fills one empty voxel; diffusion moves one
     e.close()
+
+
+def test_supersteps_vs_oracle_128(oracle_mod):
+    """128^3, box 8 (4096 boxes), 10 super-steps = all eight octants + a temperature update: per-box events,
+    executed counts and every field equal the CPU comparator's."""
+    import os
+
+    import cetkmc
+    from cetkmc import synthetic
+    L, box, n = 128, 8, 10
+    st, th, ph, T, df = synthetic.planes(L, 0, L, seed=8)
+    q = synthetic.laser_planes(L, 15, n)
+    e = cetkmc.Engine(L, impurity_c=0.2, n_slabs=2)
+    e.upload_planes(0, L, st, th, ph, T, df)
+    e.set_prev_state(None)
+    rg = e.run_supersteps(15, n, box, 3e-3, seed=77, thermal_mode=2, q_planes=q, want_events=True)
+    d = e.download()
+    e.close()
+    oracle_mod.set_threads(min(16, os.cpu_count() or 1))
+    try:
+        lat = oracle_mod.Lattice(st.astype(np.int64), th, ph, T, df.astype(np.int64), impurity_c=0.2)
+        ro = lat.run_supersteps(15, n, box, 3e-3, 77, thermal_mode=2, q_planes=q)
+    finally:
+        oracle_mod.set_threads(1)
+    assert rg["done"] == ro["done"] == n
+    for f in ("type", "pos", "target", "atom"):
+        assert np.array_equal(rg["events"][f], ro["events"][f]), f
+    assert np.array_equal(rg["n_exec"], ro["n_exec"]) and rg["n_exec"].min() > 2000
+    assert relerr(rg["totals"], ro["totals"]).max() <= RATE_RTOL
+    assert np.array_equal(d["state"], lat.state) and np.array_equal(d["T"], lat.T)
+    assert np.array_equal(d["theta"], lat.theta) and np.array_equal(d["phi"], lat.phi)
