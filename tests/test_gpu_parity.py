@@ -605,3 +605,31 @@ def test_long_run_vs_oracle(oracle_mod, incremental):
     for a, b in zip(g.final(), o.final()):
         assert np.array_equal(a, b)
     assert tg == to
+
+
+def test_incremental_256_vs_oracle(oracle_mod):
+    """The bench workload itself (256^3, laser mode, counter species draw), 45 steps of exact incremental stepping:
+    chosen events, counts and totals equal the oracle's full evaluation of every step."""
+    import cetkmc
+    from cetkmc import synthetic
+    L, n = 256, 45
+    st, th, ph, T, df = synthetic.planes(L, 0, L, seed=42)
+    rs = np.random.RandomState(6)
+    u_pick, u_def, u_np = rs.random_sample(n), rs.random_sample(n), rs.random_sample(2 * n + 2)
+    q = synthetic.laser_planes(L, 0, n)
+    e = cetkmc.Engine(L, impurity_c=0.2)
+    e.upload_planes(0, L, st, th, ph, T, df)
+    e.set_prev_state(None)
+    rg = e.run_steps(0, n, 3e-3, u_pick, u_def, u_np, rng_mode=1, seed=42, thermal_mode=2, q_planes=q, incremental=True)
+    e.close()
+    assert rg["done"] == n and rg["full_sweeps"] == 3
+    oracle_mod.set_threads(min(16, os.cpu_count() or 1))
+    try:
+        lat = oracle_mod.Lattice(st.astype(np.int64), th, ph, T, df.astype(np.int64), impurity_c=0.2)
+        ro = lat.run_steps(0, n, 3e-3, u_pick, u_def, u_np, rng_mode=1, seed=42, thermal_mode=2, q_planes=q)
+    finally:
+        oracle_mod.set_threads(1)
+    for f in ("type", "pos", "target", "atom"):
+        assert np.array_equal(rg["events"][f], ro["events"][f]), f
+    assert np.array_equal(rg["n_events"], ro["n_events"])
+    assert relerr(rg["totals"], ro["totals"]).max() <= RATE_RTOL
