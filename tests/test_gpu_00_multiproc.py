@@ -72,7 +72,8 @@ def _worker(rank, world, port, L, n, seed, mode, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,L,mode", [(2, 16, "full"), (3, 24, "full"), (2, 20, "incremental"), (2, 16, "laser")])
+@pytest.mark.parametrize("world,L,mode", [(2, 16, "full"), (3, 24, "full"), (2, 20, "incremental"), (2, 16, "laser"),
+                                          (4, 64, "laser")])
 def test_ranks_sharing_one_gpu_match_single_process(world, L, mode, tmp_path):
     import torch.multiprocessing as mp
     n = 70
