@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--no-incremental", action="store_true", help="skip the extra exact-incremental-mode run")
     ap.add_argument("--no-mode-b", action="store_true", help="skip the extra Mode B (super-step) run")
     ap.add_argument("--no-phases", action="store_true", help="skip the extra per-phase timing run")
+    ap.add_argument("--transport", choices=["rccl", "host"], default="rccl",
+                    help="N > 1: RCCL over xGMI (default) or the host-relay transport (ranks may share one GPU; rehearsal only)")
     ap.add_argument("--set-option", action="append", default=[], metavar="KEY=INT", help="cetkmc_set_option before the run")
     ap.add_argument("--overlap-interface", type=int, default=-1,
                     help="speculative interface evaluation of the next step during select/collectives: 1 on, 0 off (default: engine default = off)")
@@ -132,12 +134,17 @@ def main():
         if "RANK" not in os.environ:             # plain `python bench.py --force-dist`
             os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
         dist.init_process_group("gloo")          # control plane only (id exchange, barrier, max)
-        box = [cetkmc.Engine.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        uid = box[0]
+        if a.transport == "rccl":
+            box = [cetkmc.Engine.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            uid = box[0]
         # one GPU per rank; if the launcher narrowed device visibility to one GPU per process, that GPU is index 0
         dev = local_rank % max(1, cetkmc.device_count())
-        eng = cetkmc.Engine(L, impurity_c=IMPURITY_C, device=dev, rank=rank, nranks=N, unique_id=uid)
+        if a.transport == "host":     # rehearsal on a one-GPU box: ranks share the GPU, collectives relayed through gloo
+            from cetkmc import host_transport
+            eng = cetkmc.Engine(L, impurity_c=IMPURITY_C, device=dev, rank=rank, nranks=N, host_comm=host_transport.torch_callbacks())
+        else:
+            eng = cetkmc.Engine(L, impurity_c=IMPURITY_C, device=dev, rank=rank, nranks=N, unique_id=uid)
     else:
         eng = cetkmc.Engine(L, impurity_c=IMPURITY_C, device=0)
 
