@@ -309,12 +309,12 @@ __device__ __forceinline__ void sweep_row(const StreamArgs& A, const double* kta
                     wc = A.ifc_cnt[trow + h];
                     cdiff += wc;
                 }
-                if (WV) {
+                if (WV && wv_row) {     // uniform per row: rows outside the active octants run the plain loop
                     // every voxel's EMPTY-or-DIFF sum goes back (interface voxels: the value just loaded), one
                     // 16-byte + one 2-byte store per voxel pair
                     const double wv = empty ? ev : dv;
                     if (!(h & 1)) { pw = wv; pc = wc; }
-                    else if (k0 + h - 1 < L && wv_row && (!A.wv_box || wv_k(k0 + h - 1) || wv_k(k0 + h))) {
+                    else if (k0 + h - 1 < L && (!A.wv_box || wv_k(k0 + h - 1) || wv_k(k0 + h))) {
                         *reinterpret_cast<double2*>(A.ifc_val + trow + h - 1) = make_double2(pw, wv);
                         *reinterpret_cast<uint16_t*>(A.ifc_cnt + trow + h - 1) = (uint16_t)(pc | (wc << 8));
                     }
