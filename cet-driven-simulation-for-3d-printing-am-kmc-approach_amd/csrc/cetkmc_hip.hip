@@ -467,6 +467,18 @@ StreamArgs stream_args(Handle* h, const SlabView& v)
     return sa;
 }
 
+// the interface lists grow while stepping: keep the interface kernel's grid at one entry per thread (called where the
+// host has just synchronised anyway)
+int refresh_ifc_grid(Handle* h)
+{
+    for (auto& sl : h->slabs) {
+        int n_list = 0;
+        HIPCHK(hipMemcpy(&n_list, sl.v.ifc_n, sizeof(int), hipMemcpyDeviceToHost));
+        h->ifc_blocks = std::max(h->ifc_blocks, std::min(8192, (n_list + 255) / 256 + 64));
+    }
+    return 0;
+}
+
 // ---- collectives: RCCL on the stream, or relayed through host callbacks (bring-up / test transport) ------
 inline bool multi_rank(const Handle* h) { return h->comm != nullptr || h->hc.allgather != nullptr; }
 
@@ -1192,6 +1204,7 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
     if (events && done > 0) HIPCHK(hipMemcpy(events, h->d_log_event, (size_t)done * sizeof(cetkmc_event), hipMemcpyDeviceToHost));
     if (n_events && done > 0) HIPCHK(hipMemcpy(n_events, h->d_log_nev, (size_t)done * 8, hipMemcpyDeviceToHost));
     h->cnt.bytes_d2h += (totals ? done * 8 : 0) + (events ? done * (int64_t)sizeof(cetkmc_event) : 0) + (n_events ? done * 8 : 0);
+    CHK(refresh_ifc_grid(h));
     return 0;
 }
 
@@ -1311,6 +1324,7 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     res->wall_ms = ms; res->sweep_ms_total = 0.0; res->sweep_launches = 0; res->full_sweeps = n;
     h->cnt.supersteps += ss.cur;
+    CHK(refresh_ifc_grid(h));
     const int64_t done = ss.cur;
     if (totals && done > 0) HIPCHK(hipMemcpy(totals, h->d_log_total, (size_t)done * 8, hipMemcpyDeviceToHost));
     if (totals && ss.status == 1 && done < n) totals[done] = ss.total;
