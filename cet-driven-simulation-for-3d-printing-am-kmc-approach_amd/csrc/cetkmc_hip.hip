@@ -653,7 +653,7 @@ int launch_thermal(Handle* h, double dt, int laser, const double* d_q, int use_l
         if (h->thermal_variant == 1) {
             dim3 grid((h->L + THERM_KT - 1) / THERM_KT, (h->L + THERM_TJ - 1) / THERM_TJ, (v.nloc + h->therm_ni - 1) / h->therm_ni);
             hipLaunchKernelGGL(k_thermal_march, grid, dim3(256), 0, h->stream, v, (const double*)h->slabs[s].Tbuf[h->cur],
-                               h->slabs[s].Tbuf[nxt], (const uint8_t*)h->slabs[s].prev, d_q, C,
+                               h->slabs[s].Tbuf[nxt], h->slabs[s].prev, d_q, C,
                                batch ? (const StepState*)h->d_ss : nullptr);
         } else {
             dim3 grid((h->L + 255) / 256, h->L, v.nloc);
@@ -664,7 +664,7 @@ int launch_thermal(Handle* h, double dt, int laser, const double* d_q, int use_l
     }
     HIPCHK(hipGetLastError());
     CHK(exchange_T_halo(h, nxt));
-    if (laser && use_latent)
+    if (laser && use_latent && h->thermal_variant != 1)     // the marching kernel updates prev_state itself
         for (auto& s : h->slabs) HIPCHK(hipMemcpyAsync(s.prev, s.v.state, s.nS, hipMemcpyDeviceToDevice, h->stream));
     h->cur = nxt;
     h->swept = false;

@@ -1161,7 +1161,7 @@ __global__ __launch_bounds__(256) void k_thermal(SlabView S, const double* __res
 // neighbours.  Every T value is read ~1.4x and written once (k_thermal: 7 reads through L2).
 constexpr int THERM_TJ = 8, THERM_NI = 4, THERM_KT = 256;
 __global__ __launch_bounds__(256) void k_thermal_march(SlabView S, const double* __restrict__ Tin, double* __restrict__ Tout,
-                                                       const uint8_t* __restrict__ prev_state, const double* __restrict__ q_top,
+                                                       uint8_t* __restrict__ prev_state, const double* __restrict__ q_top,
                                                        ThermalCfg C, const StepState* __restrict__ ss)
 {
     constexpr int TJ = THERM_TJ, KT = THERM_KT, LW = KT + 2;
@@ -1214,6 +1214,15 @@ __global__ __launch_bounds__(256) void k_thermal_march(SlabView S, const double*
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = rbase + 2 * q, j = j0 + r;
+            // latent-heat term: states of the thread's two columns now and at the previous update, one 16-bit load each
+            // (k0 is even, rows are padded); prev_state of the next update is written back the same way (:100)
+            unsigned st2 = 0, pv2 = 0;
+            if (C.laser && C.use_latent && !passthrough && j < L && k0 < L) {
+                const int64_t sc = S.sidx(li, j, k0);
+                st2 = *reinterpret_cast<const uint16_t*>(S.state + sc);
+                pv2 = *reinterpret_cast<const uint16_t*>(prev_state + sc);
+                *reinterpret_cast<uint16_t*>(prev_state + sc) = (uint16_t)st2;
+            }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int k = k0 + h;
@@ -1234,14 +1243,13 @@ __global__ __launch_bounds__(256) void k_thermal_march(SlabView S, const double*
                     if (!C.laser) {
                         nt = tc + (C.dt * C.alpha) * lap;
                     } else {
+                        // q/(rho cp) and dF/dt are zero for almost every voxel: 0/x is +0 exactly, so the two fp64
+                        // divisions are only performed where the numerator is not zero (same bits as thermal_solver.py:99-103)
                         const double qv = (i == L - 1) ? q_top[(int64_t)j * L + k] : 0.0;
+                        const double qterm = (qv != 0.0) ? qv / C.rho_cp : 0.0;
                         double dF = 0.0;
-                        if (C.use_latent) {
-                            const int64_t sc = S.sidx(li, j, k);
-                            dF = (prev_state[sc] == 0 && S.state[sc] != 0) ? 1.0 : 0.0;
-                        }
-                        dF = dF / dtm;
-                        const double dTdt = C.alpha * lap + qv / C.rho_cp + C.latent_coef * dF;
+                        if (C.use_latent && ((pv2 >> (8 * h)) & 255u) == 0 && ((st2 >> (8 * h)) & 255u) != 0) dF = 1.0 / dtm;
+                        const double dTdt = C.alpha * lap + qterm + C.latent_coef * dF;
                         nt = tc + C.dt * dTdt;
                     }
                     double v = nt < C.clip_lo ? C.clip_lo : nt;
