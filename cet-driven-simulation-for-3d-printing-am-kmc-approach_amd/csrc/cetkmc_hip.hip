@@ -316,6 +316,21 @@ struct DevTmp {
     operator T*() const { return p; }
 };
 
+// interface list of one slab / every slab rebuilt from the membership flags, in address order
+int relist_slab(Handle* h, int sl)
+{
+    SlabView v = view_of(h, sl);
+    HIPCHK(hipMemsetAsync(v.ifc_n, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_ifc_relist, dim3((v.nloc * h->L + RELIST_ROWS - 1) / RELIST_ROWS), dim3(256), 0, h->stream, v, (const StepState*)nullptr);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int relist(Handle* h)
+{
+    for (size_t sl = 0; sl < h->slabs.size(); ++sl) CHK(relist_slab(h, (int)sl));
+    return 0;
+}
+
 // extended (owned + halo, clipped) global plane range of a slab
 void ext_range(const Handle* h, const Slab& s, int* a, int* b)
 {
@@ -397,8 +412,8 @@ int upload_impl(Handle* h, int i_begin, int i_end, const I* state, const double*
             CHK(h2d_u8<I>(h, s, s.v.state, state, i_begin, a, b, true, 1));
             HIPCHK(hipMemcpyAsync(s.prev, s.v.state, s.nS, hipMemcpyDeviceToDevice, h->stream));
             HIPCHK(hipMemsetAsync(s.v.ifc_in, 0, s.nT, h->stream));
-            HIPCHK(hipMemsetAsync(s.v.ifc_n, 0, sizeof(int), h->stream));
             hipLaunchKernelGGL(k_ifc_rebuild, dim3(2048), dim3(256), 0, h->stream, s.v);
+            CHK(relist_slab(h, (int)(&s - h->slabs.data())));
         }
         if (defects) CHK(h2d_u8<I>(h, s, s.v.defects, defects, i_begin, a, b, true));
         if (theta) CHK(h2d_f64(h, s, s.v.theta, theta, i_begin, a, b));
@@ -406,17 +421,9 @@ int upload_impl(Handle* h, int i_begin, int i_end, const I* state, const double*
         if (T) CHK(h2d_f64(h, s, s.Tbuf[h->cur], T, i_begin, a, b));
         if (theta || phi) hipLaunchKernelGGL(k_orient, dim3(1024), dim3(256), 0, h->stream, s.v);
         if (state) {
-            // order the rebuilt list by (plane,row,column): consecutive lanes of k_interface then
-            // gather from neighbouring addresses
             int n = 0;
             HIPCHK(hipMemcpyAsync(&n, s.v.ifc_n, sizeof(int), hipMemcpyDeviceToHost, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
-            if (n > 1) {
-                std::vector<uint32_t> lst((size_t)n);
-                HIPCHK(hipMemcpy(lst.data(), s.v.ifc_list, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-                std::sort(lst.begin(), lst.end());
-                HIPCHK(hipMemcpy(s.v.ifc_list, lst.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
-            }
             h->ifc_blocks = std::max(h->ifc_blocks, std::min(8192, (n + 255) / 256 + 64));
         }
     }
@@ -905,8 +912,8 @@ int cetkmc_set_prev_state(void* handle, const int64_t* prev_state)
         } else {
             HIPCHK(hipMemcpyAsync(s.prev, s.v.state, s.nS, hipMemcpyDeviceToDevice, h->stream));
             HIPCHK(hipMemsetAsync(s.v.ifc_in, 0, s.nT, h->stream));
-            HIPCHK(hipMemsetAsync(s.v.ifc_n, 0, sizeof(int), h->stream));
             hipLaunchKernelGGL(k_ifc_rebuild, dim3(2048), dim3(256), 0, h->stream, s.v);
+            CHK(relist_slab(h, (int)(&s - h->slabs.data())));
         }
     }
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1218,18 +1225,6 @@ int cetkmc_get_counters(void* handle, cetkmc_counters* out, int reset)
 }
 
 // ---- Mode B: synchronous super-steps over spatial boxes (superstep.hpp) ------------------------------
-// interface list of every slab rebuilt from the membership flags, in address order
-int relist(Handle* h)
-{
-    for (size_t sl = 0; sl < h->slabs.size(); ++sl) {
-        SlabView v = view_of(h, (int)sl);
-        HIPCHK(hipMemsetAsync(v.ifc_n, 0, sizeof(int), h->stream));
-        hipLaunchKernelGGL(k_ifc_relist, dim3((v.nloc * h->L + RELIST_ROWS - 1) / RELIST_ROWS), dim3(256), 0, h->stream, v, (const StepState*)nullptr);
-    }
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
 int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_result* res, double* totals,
                           cetkmc_event* events, int64_t* n_executed)
 {

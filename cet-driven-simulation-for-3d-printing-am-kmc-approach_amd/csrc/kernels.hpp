@@ -719,7 +719,8 @@ __device__ __forceinline__ void ifc_append(const SlabView& S, int lp, int j, int
     const int pos = atomicAdd(S.ifc_n, 1);
     S.ifc_list[pos] = ((unsigned)lp << 20) | ((unsigned)j << 10) | (unsigned)k;
 }
-// full rebuild (upload): grid-stride over the owned voxels
+// full rebuild (upload): membership flags and neighbourhood words of all owned voxels; the list itself is then
+// written in address order by k_ifc_relist (one atomic per 32 rows instead of one per entry)
 __global__ void k_ifc_rebuild(SlabView S)
 {
     const int L = S.L;
@@ -730,7 +731,7 @@ __global__ void k_ifc_rebuild(SlabView S)
         const int j = (int)(t % L), lp = (int)(t / L);
         bool hit;
         const unsigned code = ifc_encode(S, lp + 2, j, k, &hit);
-        if (hit) { ifc_append(S, lp, j, k); S.ifc_code[S.tidx(lp + 2, j, k)] = code; }
+        if (hit) { const int64_t t = S.tidx(lp + 2, j, k); S.ifc_in[t] = 1; S.ifc_code[t] = code; }     // list: k_ifc_relist
     }
 }
 // after an event changed voxel (i,j,k): it and its 14 neighbours may have become interface voxels,
