@@ -287,8 +287,8 @@ int create_common(const cetkmc_params* p, int L, const std::vector<std::pair<int
     HIPCHK(hipMemsetAsync(h->d_events_all, 0xFF, (size_t)G * sizeof(cetkmc_event), h->stream));   // type = -1
     HIPCHK(hipMalloc((void**)&h->d_ss, sizeof(StepState)));
     HIPCHK(hipMemsetAsync(h->d_ss, 0, sizeof(StepState), h->stream));
-    HIPCHK(hipMalloc((void**)&h->d_dirty, (1 + DIRTY_MAX) * sizeof(int)));
-    HIPCHK(hipMemsetAsync(h->d_dirty, 0, (1 + DIRTY_MAX) * sizeof(int), h->stream));
+    HIPCHK(hipMalloc((void**)&h->d_dirty, (1 + 2 * DIRTY_MAX) * sizeof(int)));     // list + per-plane arrival counters
+    HIPCHK(hipMemsetAsync(h->d_dirty, 0, (1 + 2 * DIRTY_MAX) * sizeof(int), h->stream));
     HIPCHK(hipMalloc((void**)&h->d_ktab, 225 * sizeof(double)));
     HIPCHK(hipMalloc((void**)&h->d_kp, sizeof(KParams)));
     HIPCHK(hipMalloc((void**)&h->d_flag, sizeof(int)));
@@ -512,14 +512,14 @@ int comm_allgather(Handle* h, void* buf, size_t per)
 int launch_dirty_rows(Handle* h, hipEvent_t ev_a, hipEvent_t ev_b)
 {
     if (ev_a) HIPCHK(hipEventRecord(ev_a, h->stream));
+    // dirty rows re-evaluated, their planes' block sums reduced by the last-arriving block of each plane (one launch;
+    // the arrival counters live behind the dirty list and are zero at rest)
     for (size_t s = 0; s < h->slabs.size(); ++s) {
         SlabView v = view_of(h, (int)s);
-        hipLaunchKernelGGL(k_rows_eval, dim3(24), dim3(64), 0, h->stream, stream_args(h, v), h->d_ktab, (const int*)h->d_dirty, (const StepState*)h->d_ss);
+        hipLaunchKernelGGL(k_rows_eval, dim3(24), dim3(256), 0, h->stream, stream_args(h, v), h->d_ktab, (const int*)h->d_dirty,
+                           (const StepState*)h->d_ss, h->d_blocks, h->d_dirty + 1 + DIRTY_MAX);
     }
     if (ev_b) HIPCHK(hipEventRecord(ev_b, h->stream));
-    for (size_t s = 0; s < h->slabs.size(); ++s)
-        hipLaunchKernelGGL(k_plane_reduce_dirty, dim3(24 * 3), dim3(64), 0, h->stream, view_of(h, (int)s), h->d_blocks,
-                           (const int*)h->d_dirty, (const StepState*)h->d_ss);
     HIPCHK(hipGetLastError());
     if (multi_rank(h)) CHK(comm_allgather(h, h->d_blocks, (size_t)3 * (h->L / h->nranks) * sizeof(BlockEnt)));
     h->swept = true;

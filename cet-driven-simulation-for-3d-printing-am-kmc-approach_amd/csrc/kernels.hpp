@@ -209,6 +209,36 @@ __global__ __launch_bounds__(256) void k_sweep_simple(KParams P, SlabView S, con
 constexpr int STREAM_NI = 8;      // planes per block
 constexpr int STREAM_MAXCH = 4;   // chunks of 256 voxels per row (L <= 1024)
 
+// Block sum of (owned plane lp, category c) by one wave: balanced tree over j of the row sums.  COH: some row sums
+// were written by other blocks of the SAME launch (k_rows_eval's in-launch reduction) -> agent-scope loads.
+template <bool COH>
+__device__ __forceinline__ void plane_reduce_wave(const double* rowsum, const int32_t* rowcnt, BlockEnt* blocks,
+                                                  int L, int Pk, int gi0, int lp, int c, int lane)
+{
+    const int b = lp * 3 + c;
+    const int nch = Pk > 64 ? (Pk >> 6) : 1;
+    double stk[5];
+    double tot = 0.0;
+    int64_t cnt = 0;
+    for (int m = 0; m < nch; ++m) {
+        const int j = (m << 6) + lane;
+        double v = 0.0;
+        int cv = 0;
+        if (j < L) {
+            if (COH) {
+                v = __hip_atomic_load(rowsum + (int64_t)b * L + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cv = __hip_atomic_load(rowcnt + (int64_t)b * L + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                v = rowsum[(int64_t)b * L + j]; cv = rowcnt[(int64_t)b * L + j];
+            }
+        }
+        v = wave_tree_sum(v);
+        cnt += wave_sum_i(cv);
+        tot = stack_push(stk, v, m);
+    }
+    if (lane == 0) { blocks[3 * (gi0 + lp) + c].sum = tot; blocks[3 * (gi0 + lp) + c].cnt = cnt; }
+}
+
 struct StreamArgs {
     double T_melt, delta_T_c, kT, I0, rate_threshold, nu_dep;
     int L, gi0, nloc, RJ, pitchC, pitchT, Pk, group_first, group_count;
@@ -410,72 +440,50 @@ __global__ __launch_bounds__(256) CETKMC_SWEEP_ATTR void k_sweep_stream(StreamAr
 // memory -- with the same sweep_row() as the streaming kernel, so every row sum equals what a full sweep
 // would have produced.  dirty[0] = count, dirty[1..] = (global plane << 16) | row.
 constexpr int DIRTY_MAX = 63;
-__global__ __launch_bounds__(64) void k_rows_eval(StreamArgs A, const double* __restrict__ ktab_g, const int* __restrict__ dirty,
-                                                  const StepState* __restrict__ ss)
+__global__ __launch_bounds__(256) void k_rows_eval(StreamArgs A, const double* __restrict__ ktab_g, const int* __restrict__ dirty,
+                                                   const StepState* __restrict__ ss, BlockEnt* __restrict__ blocks, int* plane_cnt)
 {
     if (ss && ss->status) return;
     __shared__ double ktab[226];
     __shared__ double rp[3 * STREAM_MAXCH];
-    if ((int)blockIdx.x >= dirty[0]) return;
+    __shared__ int sh_last;
+    const int n_dirty = dirty[0];
+    if ((int)blockIdx.x >= n_dirty) return;
     const int e = dirty[1 + blockIdx.x];
     const int i = e >> 16, j = e & 0xFFFF;
     const int lp = i - A.gi0;
     if (lp < 0 || lp >= A.nloc) return;                     // another slab's row
-    const int lane = threadIdx.x;
-    for (int t = lane; t < 225; t += 64) ktab[t] = ktab_g[t];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid < 225) ktab[tid] = ktab_g[tid];
     __syncthreads();
-    const int li = lp + 2;
-    const int nch = A.Pk > 256 ? (A.Pk >> 8) : 1;
-    auto rowp = [&](int d, int dj) { return A.cls + ((int64_t)(li + d) * A.RJ + (j + 2 + dj)) * A.pitchC + KOFFC; };
-    sweep_row<false>(A, ktab, rp, rowp, li, lp, j, A.gi0 + lp == A.L - 1, lane, nch);
-}
-// block sums of the planes that own a dirty row (duplicates recompute the same value)
-__global__ __launch_bounds__(64) void k_plane_reduce_dirty(SlabView S, BlockEnt* __restrict__ blocks, const int* __restrict__ dirty,
-                                                           const StepState* __restrict__ ss)
-{
-    if (ss && ss->status) return;
-    const int e_idx = blockIdx.x / 3, c = blockIdx.x - 3 * e_idx;
-    if (e_idx >= dirty[0]) return;
-    const int lp = (dirty[1 + e_idx] >> 16) - S.gi0;
-    if (lp < 0 || lp >= S.nloc) return;
-    const int b = lp * 3 + c, lane = threadIdx.x;
-    const int nch = S.Pk > 64 ? (S.Pk >> 6) : 1;
-    double stk[5];
-    double tot = 0.0;
-    int64_t cnt = 0;
-    for (int m = 0; m < nch; ++m) {
-        const int j = (m << 6) + lane;
-        double v = 0.0;
-        int cv = 0;
-        if (j < S.L) { v = S.rowsum[(int64_t)b * S.L + j]; cv = S.rowcnt[(int64_t)b * S.L + j]; }
-        v = wave_tree_sum(v);
-        cnt += wave_sum_i(cv);
-        tot = stack_push(stk, v, m);
+    if (w == 0) {
+        const int li = lp + 2;
+        const int nch = A.Pk > 256 ? (A.Pk >> 8) : 1;
+        auto rowp = [&](int d, int dj) { return A.cls + ((int64_t)(li + d) * A.RJ + (j + 2 + dj)) * A.pitchC + KOFFC; };
+        sweep_row<false>(A, ktab, rp, rowp, li, lp, j, A.gi0 + lp == A.L - 1, lane, nch);
     }
-    if (lane == 0) { blocks[3 * (S.gi0 + lp) + c].sum = tot; blocks[3 * (S.gi0 + lp) + c].cnt = cnt; }
+    __syncthreads();
+    // the block that finishes a plane's last dirty row reduces that plane's three category blocks (waves 0..2);
+    // the plane's counter is the slot of its first entry in the list
+    if (tid == 0) {
+        int first = -1, n_plane = 0;
+        for (int q = 0; q < n_dirty; ++q)
+            if ((dirty[1 + q] >> 16) == i) { if (first < 0) first = q; ++n_plane; }
+        __threadfence();
+        const int prev = __hip_atomic_fetch_add(plane_cnt + first, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        sh_last = (prev == n_plane - 1);
+        if (sh_last) plane_cnt[first] = 0;
+    }
+    __syncthreads();
+    if (sh_last && w < 3) plane_reduce_wave<true>(A.rowsum, A.rowcnt, blocks, A.L, A.Pk, A.gi0, lp, w, lane);
 }
-
 // k_plane_reduce: one wave per (owned plane, category): balanced tree over j of the row sums.
 __global__ __launch_bounds__(64) void k_plane_reduce(SlabView S, BlockEnt* __restrict__ blocks,
                                                      const StepState* __restrict__ ss)
 {
     if (ss && ss->status) return;
-    const int b = blockIdx.x, lane = threadIdx.x;
-    const int lp = b / 3, c = b - lp * 3;
-    const int nch = S.Pk > 64 ? (S.Pk >> 6) : 1;
-    double stk[5];
-    double tot = 0.0;
-    int64_t cnt = 0;
-    for (int m = 0; m < nch; ++m) {
-        const int j = (m << 6) + lane;
-        double v = 0.0;
-        int cv = 0;
-        if (j < S.L) { v = S.rowsum[(int64_t)b * S.L + j]; cv = S.rowcnt[(int64_t)b * S.L + j]; }
-        v = wave_tree_sum(v);
-        cnt += wave_sum_i(cv);
-        tot = stack_push(stk, v, m);
-    }
-    if (lane == 0) { blocks[3 * (S.gi0 + lp) + c].sum = tot; blocks[3 * (S.gi0 + lp) + c].cnt = cnt; }
+    const int b = blockIdx.x;
+    plane_reduce_wave<false>(S.rowsum, S.rowcnt, blocks, S.L, S.Pk, S.gi0, b / 3, b % 3, (int)threadIdx.x);
 }
 
 // ---- LDS heap tree helpers (leaves at [P,2P), node n has children 2n, 2n+1) -------------
