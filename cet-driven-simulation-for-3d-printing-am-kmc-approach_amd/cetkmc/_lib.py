@@ -74,11 +74,15 @@ class RunResult(C.Structure):
     ]
 
 
+STRUCT_MIRRORS = {"params": Params, "event": Event, "sweep_info": SweepInfo, "run_args": RunArgs, "run_result": RunResult,
+                  "super_args": SuperArgs, "counters": Counters, "host_comm": HostComm}
+
 # name -> (restype, argtypes); every symbol include/cetkmc.h declares
 _P = C.POINTER
 PROTOTYPES = {
     "cetkmc_last_error": (C.c_char_p, []),
     "cetkmc_abi_version": (C.c_int, []),
+    "cetkmc_struct_size": (C.c_int, [C.c_char_p]),
     "cetkmc_device_count": (C.c_int, [_P(C.c_int)]),
     "cetkmc_create": (C.c_int, [_P(Params), C.c_int, C.c_int, _P(C.c_int), _P(C.c_void_p)]),
     "cetkmc_get_unique_id": (C.c_int, [C.c_char_p]),
@@ -150,5 +154,9 @@ def load():
         fn.argtypes = args
     if lib.cetkmc_abi_version() != 1:
         raise RuntimeError("libcetkmc_hip.so ABI version mismatch")
+    for name, mirror in STRUCT_MIRRORS.items():
+        if lib.cetkmc_struct_size(name.encode()) != C.sizeof(mirror):
+            raise RuntimeError(f"libcetkmc_hip.so: struct {name} is {lib.cetkmc_struct_size(name.encode())} bytes, "
+                               f"the Python mirror {C.sizeof(mirror)} (stale build?)")
     _lib = lib
     return lib

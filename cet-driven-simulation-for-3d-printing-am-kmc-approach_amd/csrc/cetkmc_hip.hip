@@ -726,6 +726,17 @@ extern "C" {
 const char* cetkmc_last_error(void) { return g_err.c_str(); }
 int cetkmc_abi_version(void) { return CETKMC_ABI_VERSION; }
 
+int cetkmc_struct_size(const char* name)
+{
+    if (!name) return -1;
+#define SZ(n, t) if (!strcmp(name, n)) return (int)sizeof(t)
+    SZ("params", cetkmc_params); SZ("event", cetkmc_event); SZ("sweep_info", cetkmc_sweep_info);
+    SZ("run_args", cetkmc_run_args); SZ("run_result", cetkmc_run_result); SZ("super_args", cetkmc_super_args);
+    SZ("counters", cetkmc_counters); SZ("host_comm", cetkmc_host_comm);
+#undef SZ
+    return -1;
+}
+
 int cetkmc_device_count(int* n)
 {
     if (!n) return fail("null argument");

@@ -153,6 +153,9 @@ typedef struct cetkmc_counters {
 
 const char* cetkmc_last_error(void);
 int cetkmc_abi_version(void);
+/* sizeof of an ABI struct by name ("params", "event", "sweep_info", "run_args", "run_result", "super_args", "counters",
+ * "host_comm"); -1 for an unknown name.  Lets a binding check its mirrors against the library it loaded. */
+int cetkmc_struct_size(const char* name);
 int cetkmc_device_count(int* n);
 
 /* Lifetime.  n_slabs > 1 with all device_ids equal splits the lattice into axis-0 slabs

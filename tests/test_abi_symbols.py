@@ -60,3 +60,14 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not pat.search(src), os.path.join(dirpath, f)
+
+
+def test_struct_sizes_match_python_mirrors():
+    """cetkmc_struct_size: every ABI struct has the size of its ctypes mirror (the loader enforces it too)."""
+    import ctypes as C
+
+    from cetkmc import _lib
+    lib = _lib.load()
+    for name, mirror in _lib.STRUCT_MIRRORS.items():
+        assert lib.cetkmc_struct_size(name.encode()) == C.sizeof(mirror), name
+    assert lib.cetkmc_struct_size(b"no_such_struct") == -1
