@@ -170,7 +170,10 @@ __global__ __launch_bounds__(64) void k_domain_slot_apply(KParams P, const SlabV
 // interface kernel itself runs only on super-steps that follow a temperature update (and on the first of a
 // batch); the list is rebuilt in address order by k_ifc_relist right before it (k_interface is bound by the
 // locality of its gathers, Mode B lists are long).
-__global__ __launch_bounds__(256) void k_domain_touch(KParams P, const SlabView* __restrict__ slabs, int nslabs, int D,
+#ifndef CETKMC_TOUCH_ATTR
+#define CETKMC_TOUCH_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))    // 145 VGPRs otherwise (3 waves/SIMD): -10 us per super-step
+#endif
+__global__ __launch_bounds__(256) CETKMC_TOUCH_ATTR void k_domain_touch(KParams P, const SlabView* __restrict__ slabs, int nslabs, int D,
                                                       const cetkmc_event* __restrict__ dom_events, const StepState* __restrict__ ss,
                                                       const double* __restrict__ ktab_g)
 {
