@@ -248,6 +248,8 @@ int create_common(const cetkmc_params* p, int L, const std::vector<std::pair<int
         HIPCHK(hipMalloc((void**)&s.v.state, s.nS));
         HIPCHK(hipMalloc((void**)&s.v.defects, s.nS));
         HIPCHK(hipMalloc((void**)&s.prev, s.nS));
+        HIPCHK(hipMalloc((void**)&s.v.row_chg, (size_t)(s.v.nloc + 4) * L));
+        HIPCHK(hipMemsetAsync(s.v.row_chg, 1, (size_t)(s.v.nloc + 4) * L, h->stream));
         HIPCHK(hipMemsetAsync(s.v.state, OOB, s.nS, h->stream));
         HIPCHK(hipMemsetAsync(s.v.defects, 0, s.nS, h->stream));
         HIPCHK(hipMemsetAsync(s.prev, OOB, s.nS, h->stream));
@@ -411,6 +413,7 @@ int upload_impl(Handle* h, int i_begin, int i_end, const I* state, const double*
         if (state) {
             CHK(h2d_u8<I>(h, s, s.v.state, state, i_begin, a, b, true, 1));
             HIPCHK(hipMemcpyAsync(s.prev, s.v.state, s.nS, hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(hipMemsetAsync(s.v.row_chg, 0, (size_t)(s.v.nloc + 4) * h->L, h->stream));      // prev_state == state
             HIPCHK(hipMemsetAsync(s.v.ifc_in, 0, s.nT, h->stream));
             hipLaunchKernelGGL(k_ifc_rebuild, dim3(2048), dim3(256), 0, h->stream, s.v);
             CHK(relist_slab(h, (int)(&s - h->slabs.data())));
@@ -671,8 +674,14 @@ int launch_thermal(Handle* h, double dt, int laser, const double* d_q, int use_l
     }
     HIPCHK(hipGetLastError());
     CHK(exchange_T_halo(h, nxt));
-    if (laser && use_latent && h->thermal_variant != 1)     // the marching kernel updates prev_state itself
-        for (auto& s : h->slabs) HIPCHK(hipMemcpyAsync(s.prev, s.v.state, s.nS, hipMemcpyDeviceToDevice, h->stream));
+    if (laser && use_latent) {
+        for (auto& s : h->slabs) {
+            if (h->thermal_variant != 1)      // the marching kernel brings prev_state level with state itself (changed rows)
+                HIPCHK(hipMemcpyAsync(s.prev, s.v.state, s.nS, hipMemcpyDeviceToDevice, h->stream));
+            hipLaunchKernelGGL(k_clear_row_flags, dim3(64), dim3(256), 0, h->stream, s.v, batch ? (const StepState*)h->d_ss : nullptr);
+        }
+        HIPCHK(hipGetLastError());
+    }
     h->cur = nxt;
     h->swept = false;
     return 0;
@@ -697,7 +706,7 @@ void destroy_impl(Handle* h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     for (auto& s : h->slabs) {
-        (void)hipFree(s.v.state); (void)hipFree(s.v.defects); (void)hipFree(s.prev); (void)hipFree(s.v.cls);
+        (void)hipFree(s.v.state); (void)hipFree(s.v.defects); (void)hipFree(s.prev); (void)hipFree(s.v.row_chg); (void)hipFree(s.v.cls);
         (void)hipFree(s.Tbuf[0]); (void)hipFree(s.Tbuf[1]); (void)hipFree(s.v.theta); (void)hipFree(s.v.phi); (void)hipFree(s.v.ovec);
         (void)hipFree(s.v.rowsum); (void)hipFree(s.v.rowcnt);
         (void)hipFree(s.v.ifc_val); (void)hipFree(s.v.dep_val); (void)hipFree(s.v.ifc_cnt); (void)hipFree(s.v.ifc_in); (void)hipFree(s.v.ifc_code); (void)hipFree(s.v.ifc_list); (void)hipFree(s.v.ifc_n);
@@ -920,8 +929,10 @@ int cetkmc_set_prev_state(void* handle, const int64_t* prev_state)
             int a, b;
             ext_range(h, s, &a, &b);
             CHK(h2d_u8<int64_t>(h, s, s.prev, prev_state, 0, a, b, true));
+            HIPCHK(hipMemsetAsync(s.v.row_chg, 1, (size_t)(s.v.nloc + 4) * h->L, h->stream));      // may differ anywhere
         } else {
             HIPCHK(hipMemcpyAsync(s.prev, s.v.state, s.nS, hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(hipMemsetAsync(s.v.row_chg, 0, (size_t)(s.v.nloc + 4) * h->L, h->stream));
             HIPCHK(hipMemsetAsync(s.v.ifc_in, 0, s.nT, h->stream));
             hipLaunchKernelGGL(k_ifc_rebuild, dim3(2048), dim3(256), 0, h->stream, s.v);
             CHK(relist_slab(h, (int)(&s - h->slabs.data())));

@@ -946,6 +946,7 @@ __device__ __forceinline__ void write_site(const SlabView& S, int i, int j, int 
     const int li = i - (S.gi0 - 2);
     if (li < 0 || li >= S.nloc + 4) return;
     S.state[S.sidx(li, j, k)] = (uint8_t)st;
+    S.row_chg[(int64_t)li * S.L + j] = 1;
     S.cls[S.cidx(li, j, k)] = class16(st);
     const int64_t q = S.tidx(li, j, k);
     S.theta[q] = th; S.phi[q] = ph;
@@ -1164,6 +1165,15 @@ __global__ __launch_bounds__(256) void k_thermal(SlabView S, const double* __res
     Tout[c] = v;
 }
 
+// after a latent-heat temperature update prev_state equals state again: drop the row flags (not when the batch has
+// already terminated -- the update was then a pass-through and prev_state was left alone)
+__global__ void k_clear_row_flags(SlabView S, const StepState* __restrict__ ss)
+{
+    if (ss && ss->status) return;
+    const int64_t n = (int64_t)(S.nloc + 4) * S.L;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) S.row_chg[q] = 0;
+}
+
 // k_thermal_march: same arithmetic as k_thermal, 2.5-D blocked.  One block owns THERM_TJ rows x 256
 // columns and marches over THERM_NI planes: the planes i-1, i, i+1 of its own voxels live in registers
 // (8 voxels per thread), plane i additionally in an LDS tile with a one-voxel rim for the j+-1 / k+-1
@@ -1224,9 +1234,10 @@ __global__ __launch_bounds__(256) void k_thermal_march(SlabView S, const double*
         for (int q = 0; q < 4; ++q) {
             const int r = rbase + 2 * q, j = j0 + r;
             // latent-heat term: states of the thread's two columns now and at the previous update, one 16-bit load each
-            // (k0 is even, rows are padded); prev_state of the next update is written back the same way (:100)
+            // (k0 is even, rows are padded); prev_state of the next update is written back the same way (:100).  Only rows
+            // written since the last update can differ from prev_state (row_chg, set by write_site)
             unsigned st2 = 0, pv2 = 0;
-            if (C.laser && C.use_latent && !passthrough && j < L && k0 < L) {
+            if (C.laser && C.use_latent && !passthrough && j < L && k0 < L && S.row_chg[(int64_t)li * L + j]) {
                 const int64_t sc = S.sidx(li, j, k0);
                 st2 = *reinterpret_cast<const uint16_t*>(S.state + sc);
                 pv2 = *reinterpret_cast<const uint16_t*>(prev_state + sc);

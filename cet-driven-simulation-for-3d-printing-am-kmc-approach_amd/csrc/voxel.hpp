@@ -56,6 +56,8 @@ struct SlabView {
     int pitchC;   // u16 elements per padded class row (k=0 at KOFFC)
     uint8_t* state;     // [(nloc+4)][RJ][pitchS]
     uint8_t* defects;   // same layout
+    uint8_t* row_chg;   // [(nloc+4)][L]: 1 if a voxel of row (li, j) was written since prev_state was last brought level with
+                        // state (the latent-heat test of the temperature update only looks at such rows)
     uint16_t* cls;      // [(nloc+4)][RJ][pitchC] neighbour-census class of every voxel (class16())
     double* T;          // [(nloc+4)][L][pitchT]  (current buffer)
     double* theta;
