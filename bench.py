@@ -203,7 +203,7 @@ def main():
     timed_inputs = prepare(step, a.steps)
     barrier()
     t0 = time.perf_counter()
-    r = run(step, a.steps, profile=True, prep=timed_inputs)
+    r = run(step, a.steps, profile=3, prep=timed_inputs)      # sweep kernel timed by hipEvents on every 8th launch
     barrier()
     dt = time.perf_counter() - t0
     assert r["done"] == a.steps and r["status"] == 0, r
@@ -300,7 +300,7 @@ def main():
         "device_ms_per_step": r["wall_ms"] / a.steps,
         "roofline": {"bound": "hbm", "kernel": "k_sweep_stream", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "avg_launch_ms": sweep_ms,
+                     "avg_launch_ms": sweep_ms, "launches_timed": int(r["sweep_launches"]),   # every 8th launch of the timed region
                      "alg_bytes_per_voxel": B_ALG_SWEEP, "voxels_per_launch": n_own,
                      # BASELINE.md section 4 / SURVEY 8(d) pre-build accounting: 26.8 B per voxel per step (state u8 + T +
                      # theta + phi f64 + defects u8 streamed every sweep, thermal 16 B / 20) x steps/s.  The build does

@@ -99,7 +99,8 @@ typedef struct cetkmc_run_args {
     const double* q_planes;   /* thermal_mode 2: [n_q][L*L] source planes, consumed in order */
     int64_t n_q;
     int32_t use_latent;       /* thermal_mode 2: latent-heat term on/off                */
-    int32_t profile;          /* 1: time every rate-sweep launch with hipEvents; 2: time every phase (cetkmc_get_counters) */
+    int32_t profile;          /* 1: time every rate-sweep launch with hipEvents; 3: every 8th launch (an event record costs
+                                 ~5 us of stream time); 2: time every phase (cetkmc_get_counters) */
     int32_t incremental;      /* 0: every step evaluates the whole lattice (get_event_rates, kmc_event_rates.py:162);
                                  1: exact incremental mode -- between temperature updates only the rows whose
                                     rates the previous event can have changed are re-evaluated (identical
