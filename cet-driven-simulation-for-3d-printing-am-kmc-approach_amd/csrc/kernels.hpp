@@ -742,38 +742,6 @@ __global__ void k_ifc_rebuild(SlabView S)
         if (hit) { const int64_t t = S.tidx(lp + 2, j, k); S.ifc_in[t] = 1; S.ifc_code[t] = code; }     // list: k_ifc_relist
     }
 }
-// after an event changed voxel (i,j,k): it and its 14 neighbours may have become interface voxels,
-// and the category sums of those already listed are stale (their neighbour states / orientations
-// changed).  Called by a full wave: lane l < 15 handles one of the 15 voxels: append if needed, then
-// re-evaluate if listed -- this keeps ifc_val/ifc_cnt exact when k_interface ran BEFORE the event
-// (the speculative, overlapped launch of the batched loop).
-__device__ __forceinline__ void ifc_touch(const KParams& P, const SlabView& S, const double* ktab, int i, int j, int k, int lane,
-                                          int eval)
-{
-    if (lane >= 15) return;
-    int ai = i, aj = j, ak = k;
-    if (lane < 14) { ai += nbi_rt(lane); aj += nbj_rt(lane); ak += nbk_rt(lane); }
-    const int L = S.L;
-    if (ai < 0 || ai >= L || aj < 0 || aj >= L || ak < 0 || ak >= L) return;
-    const int lp = ai - S.gi0;
-    if (lp < 0 || lp >= S.nloc) return;                      // owned planes only
-    const int li = lp + 2;
-    bool hit;
-    const unsigned code = ifc_encode(S, li, aj, ak, &hit);
-    if (hit) ifc_append(S, lp, aj, ak);
-    const int64_t t = S.tidx(li, aj, ak);
-    if (S.ifc_in[t]) S.ifc_code[t] = code;
-    if (eval && S.ifc_in[t]) {
-        const int st = S.state[S.sidx(li, aj, ak)];
-        double sum = 0.0;
-        int cnt = 0;
-        auto nb = [&](int mm) -> int { return S.state[S.sidx(li + nbi_rt(mm), aj + nbj_rt(mm), ak + nbk_rt(mm))]; };
-        auto emit = [&](int cat, int, double rate, int, int) { if (cat != CAT_DEP) { sum += rate; ++cnt; } };
-        eval_voxel(P, S, ktab, li, ai, aj, ak, st, S.T[t], nb, emit);
-        S.ifc_val[t] = sum;
-        S.ifc_cnt[t] = (uint8_t)cnt;
-    }
-}
 // EMPTY-category sum of a listed empty voxel (nuc + attachments) / DIFF-category sum of a listed atom, from its
 // packed neighbourhood word alone
 __device__ __forceinline__ void ifc_eval_empty(const KParams& P, const SlabView& S, const double* ktab, int lp, int j, int k,
@@ -849,6 +817,38 @@ __device__ __forceinline__ void ifc_eval_atom(const KParams& P, const SlabView& 
     }
 }
 
+// after an event changed voxel (i,j,k): it and its 14 neighbours may have become interface voxels,
+// and the category sums of those already listed are stale (their neighbour states / orientations
+// changed).  Called by a full wave: lane l < 15 handles one of the 15 voxels: append if needed, then
+// re-evaluate if listed -- this keeps ifc_val/ifc_cnt exact when k_interface ran BEFORE the event
+// (the speculative, overlapped launch of the batched loop).
+__device__ __forceinline__ void ifc_touch(const KParams& P, const SlabView& S, const double* ktab, int i, int j, int k, int lane,
+                                          int eval)
+{
+    if (lane >= 15) return;
+    int ai = i, aj = j, ak = k;
+    if (lane < 14) { ai += nbi_rt(lane); aj += nbj_rt(lane); ak += nbk_rt(lane); }
+    const int L = S.L;
+    if (ai < 0 || ai >= L || aj < 0 || aj >= L || ak < 0 || ak >= L) return;
+    const int lp = ai - S.gi0;
+    if (lp < 0 || lp >= S.nloc) return;                      // owned planes only
+    const int li = lp + 2;
+    bool hit;
+    const unsigned code = ifc_encode(S, li, aj, ak, &hit);
+    if (hit) ifc_append(S, lp, aj, ak);
+    const int64_t t = S.tidx(li, aj, ak);
+    if (S.ifc_in[t]) S.ifc_code[t] = code;
+    if (eval && S.ifc_in[t]) {       // the same evaluation from the packed word as k_interface
+        const int st = (code >> 30) ? 4 : (int)((code >> 28) & 3u);
+        const double Tc = pymax(S.T[t], 1.0);
+        double sum = 0.0;
+        int cnt = 0;
+        if (st == 0) ifc_eval_empty(P, S, ktab, lp, aj, ak, t, code, Tc, sum, cnt);
+        else if (st != 4) ifc_eval_atom(P, S, lp, aj, ak, t, code, st, Tc, sum, cnt);
+        S.ifc_val[t] = sum;
+        S.ifc_cnt[t] = (uint8_t)cnt;
+    }
+}
 // deposition rates of plane L-1 as a function of temperature (every full sweep, by the interface kernels' threads)
 __device__ __forceinline__ void dep_fill(const KParams& P, const SlabView& S, int gtid, int nthreads)
 {
