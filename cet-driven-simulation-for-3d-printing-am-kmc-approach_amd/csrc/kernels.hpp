@@ -626,14 +626,19 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
     for (int k = tid; k < Pk; k += 256) {
         double sum = 0.0; int cnt = 0;
         if (k < L) {
-            const int st = S.state[S.sidx(li, j, k)];
+            // state, membership flag, stored interface sum and temperature are requested together (one round trip)
             const int64_t t = S.tidx(li, j, k);
-            if (c != CAT_DEP && ifc_ready && S.ifc_in[t]) {
-                if ((c == CAT_EMPTY) == (st == 0)) { sum = S.ifc_val[t]; cnt = S.ifc_cnt[t]; }
+            const int st = S.state[S.sidx(li, j, k)];
+            const bool listed = ifc_ready && S.ifc_in[t] != 0;
+            const double v_ifc = S.ifc_val[t];
+            const int c_ifc = S.ifc_cnt[t];
+            const double Traw = S.T[t];
+            if (c != CAT_DEP && listed) {
+                if ((c == CAT_EMPTY) == (st == 0)) { sum = v_ifc; cnt = c_ifc; }
             } else {
                 auto nb = [&](int mm) -> int { return S.state[S.sidx(li + nbi_rt(mm), j + nbj_rt(mm), k + nbk_rt(mm))]; };
                 auto emit = [&](int cat, int, double rate, int, int) { if (cat == c) { sum += rate; ++cnt; } };
-                eval_voxel(P, S, ktab, li, i, j, k, st, S.T[t], nb, emit);
+                eval_voxel(P, S, ktab, li, i, j, k, st, Traw, nb, emit);
             }
         }
         hs[Pk + k] = sum; hf[Pk + k] = cnt > 0; leafcnt[k] = cnt;
@@ -697,17 +702,20 @@ __global__ __launch_bounds__(256) void k_select(KParams P, const SlabView* __res
 // k_interface evaluates a listed voxel from this word alone (no neighbour-state gathers).
 __device__ __forceinline__ unsigned ifc_encode(const SlabView& S, int li, int j, int k, bool* interface_out)
 {
+    // all 15 states are requested at once (the padding makes every address valid), then decoded
     const int st = S.state[S.sidx(li, j, k)];
+    int sm[14];
+#pragma unroll
+    for (int m = 0; m < 14; ++m) sm[m] = S.state[S.sidx(li + nbi_rt(m), j + nbj_rt(m), k + nbk_rt(m))];
     unsigned code = 0;
     bool hit = false;
     if (st < 128 && st != 4) {
         code = (unsigned)(st & 3) << 28;
 #pragma unroll
-        for (int m = 0; m < 14; ++m) {          // unrolled: the 14 loads are issued together
-            const int sm = S.state[S.sidx(li + nbi_rt(m), j + nbj_rt(m), k + nbk_rt(m))];
+        for (int m = 0; m < 14; ++m) {
             unsigned c;
-            if (st == 0) { c = (sm >= 1 && sm <= 3) ? (unsigned)sm : 0u; hit |= (c != 0u); }
-            else { c = (sm == 0) ? 1u : ((sm != OOB) ? 2u : 0u); hit |= (sm == 0); }
+            if (st == 0) { c = (sm[m] >= 1 && sm[m] <= 3) ? (unsigned)sm[m] : 0u; hit |= (c != 0u); }
+            else { c = (sm[m] == 0) ? 1u : ((sm[m] != OOB) ? 2u : 0u); hit |= (sm[m] == 0); }
             code |= c << (2 * m);
         }
     } else {
@@ -719,8 +727,8 @@ __device__ __forceinline__ unsigned ifc_encode(const SlabView& S, int li, int j,
 __device__ __forceinline__ void ifc_append(const SlabView& S, int lp, int j, int k)
 {
     const int64_t t = S.tidx(lp + 2, j, k);
-    if (S.ifc_in[t]) return;
-    // test-and-set on the byte through its 32-bit word: several waves may touch the same voxel (Mode B)
+    // test-and-set on the byte through its 32-bit word (two lanes of an event may touch the same voxel); callers have
+    // already seen the flag clear
     unsigned* w = reinterpret_cast<unsigned*>(S.ifc_in + (t & ~(int64_t)3));
     const unsigned bit = 1u << (8 * (int)(t & 3));
     if (atomicOr(w, bit) & bit) return;
@@ -833,14 +841,17 @@ __device__ __forceinline__ void ifc_touch(const KParams& P, const SlabView& S, c
     const int lp = ai - S.gi0;
     if (lp < 0 || lp >= S.nloc) return;                      // owned planes only
     const int li = lp + 2;
+    const int64_t t = S.tidx(li, aj, ak);
+    // one memory round trip: membership flag and temperature go out together with the 15 states of ifc_encode
+    bool listed = S.ifc_in[t] != 0;
+    const double Traw = eval ? S.T[t] : 0.0;
     bool hit;
     const unsigned code = ifc_encode(S, li, aj, ak, &hit);
-    if (hit) ifc_append(S, lp, aj, ak);
-    const int64_t t = S.tidx(li, aj, ak);
-    if (S.ifc_in[t]) S.ifc_code[t] = code;
-    if (eval && S.ifc_in[t]) {       // the same evaluation from the packed word as k_interface
+    if (hit && !listed) { ifc_append(S, lp, aj, ak); listed = true; }
+    if (listed) S.ifc_code[t] = code;
+    if (eval && listed) {            // the same evaluation from the packed word as k_interface
         const int st = (code >> 30) ? 4 : (int)((code >> 28) & 3u);
-        const double Tc = pymax(S.T[t], 1.0);
+        const double Tc = pymax(Traw, 1.0);
         double sum = 0.0;
         int cnt = 0;
         if (st == 0) ifc_eval_empty(P, S, ktab, lp, aj, ak, t, code, Tc, sum, cnt);
