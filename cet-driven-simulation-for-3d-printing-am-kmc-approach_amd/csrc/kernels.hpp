@@ -554,8 +554,15 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
     __shared__ long long red[256];
     __shared__ double sh_base, sh_r;
     __shared__ int sh_go, sh_b, sh_slab, sh_j, sh_k;
+    __shared__ int sh_gi0[64], sh_nloc[64];
     const int tid = threadIdx.x;
     if (cfg.batch && ss->status) return;
+    // everything thread 0 will need after the first heap is requested now, behind the block loads: the step's uniform,
+    // the stream cursor and the slabs' plane ranges
+    double u0 = 0.0;
+    long long np_pos0 = 0;
+    if (tid == 0 && cfg.batch) { u0 = u_pick[ss->cur]; np_pos0 = ss->np_pos; }
+    if (tid < nslabs && tid < 64) { sh_gi0[tid] = slabs[tid].gi0; sh_nloc[tid] = slabs[tid].nloc; }
     const int NBk = 3 * L;
     long long csum = 0;
     for (int idx = tid; idx < PB; idx += 256) {
@@ -581,16 +588,18 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
             go = 0;
         } else if (cfg.batch && go) {
             long long need = (cfg.rng_mode == 0 ? n_dep : 0) + 2;
-            if (ss->np_pos + need > cfg.np_cap) { ss->status = 2; go = 0; }
+            if (np_pos0 + need > cfg.np_cap) { ss->status = 2; go = 0; }
         }
         if (go) {
-            const double r = cfg.batch ? u_pick[ss->cur] * total : r_direct;
+            const double r = cfg.batch ? u0 * total : r_direct;
             double base = 0.0;
             const int b = heap_descend(hs, hf, PB, base, r);
             const int i = b / 3;
             int sl = -1;
-            for (int s = 0; s < nslabs; ++s)
-                if (i >= slabs[s].gi0 && i < slabs[s].gi0 + slabs[s].nloc) sl = s;
+            for (int s = 0; s < nslabs; ++s) {
+                const int g0 = s < 64 ? sh_gi0[s] : slabs[s].gi0, nl = s < 64 ? sh_nloc[s] : slabs[s].nloc;
+                if (i >= g0 && i < g0 + nl) sl = s;
+            }
             sh_b = b; sh_slab = sl; sh_base = base; sh_r = r;
             if (sl < 0) go = 0;     // owned by another rank
         }
@@ -1103,10 +1112,13 @@ __global__ __launch_bounds__(256) void k_select_apply(KParams P, const SlabView*
                                                       double* log_total, cetkmc_event* log_event, int64_t* log_nev,
                                                       int eval_touched, int* dirty)
 {
-    select_body(P, slabs, nslabs, L, PB, blocks, ss, cfg, u_pick, 0.0, ktab_g, my_event, 0, ifc_ready);
-    __threadfence_block();
+    __shared__ cetkmc_event sh_sel;            // the chosen event goes from the selection to the application through LDS
+    (void)my_event;
+    if (threadIdx.x == 0) sh_sel.type = -1;
     __syncthreads();
-    apply_batch_body(P, slabs, nslabs, L, my_event, 1, ss, cfg, u_defect, u_np, log_total, log_event, log_nev, ktab_g,
+    select_body(P, slabs, nslabs, L, PB, blocks, ss, cfg, u_pick, 0.0, ktab_g, &sh_sel, 0, ifc_ready);
+    __syncthreads();
+    apply_batch_body(P, slabs, nslabs, L, &sh_sel, 1, ss, cfg, u_defect, u_np, log_total, log_event, log_nev, ktab_g,
                      eval_touched, dirty);
 }
 
