@@ -133,8 +133,8 @@ __device__ __forceinline__ double dep_rate(const KParams& P, double Tc)
 }
 // exp(x) for x <= 0 (NaN -> 0): round-to-nearest reduction x = n*ln2 + r, |r| <= ln2/2, degree-13
 // Taylor polynomial in Horner form (truncation 4e-18), scaled by 2^n.  About 1 ulp; no overflow path
-// (x <= 0) and underflow falls out of v_ldexp_f64.  Used for the nucleation rate, whose argument is
-// -barrier/(kT*T) <= 0 by construction.
+// (x <= 0) and underflow falls out of v_ldexp_f64.  Used for the nucleation, attachment and diffusion rates, whose
+// arguments -E/(kT*T) are <= 0 by construction (the deposition rate's can be positive: libm exp there).
 // d = a*b + c as ONE v_fma_f64 (hipcc otherwise expands a Horner step with a constant addend into
 // v_mov_b64 + v_fmac_f64, doubling the instruction count of the polynomial)
 __device__ __forceinline__ double fma1(double a, double b, double c)
@@ -223,7 +223,7 @@ __device__ __forceinline__ double att_item(const KParams& P, const AttCtx& c, do
     double dot = c.a0 * b0 + c.a1 * b1 + c.a2 * b2;
     dot = pymax(pymin(dot, 1.0), -1.0);
     const double E_att = 0.5 * P.E_b[sn - 1] * (1.0 - dot);
-    return P.nu * exp(-E_att / c.kTT) * c.aniso;
+    return P.nu * exp_nonpos(-E_att / c.kTT) * c.aniso;      // E_att >= 0: the argument is never positive
 }
 __device__ __forceinline__ double att_rate(const KParams& P, const SlabView& S, int li, int j, int k,
                                            int di, int dj, int dk, int sn, double Tc)
@@ -240,7 +240,7 @@ __device__ __forceinline__ DiffCtx diff_ctx(const KParams& P, const SlabView& S,
     const double defect_factor = 1.0 + (double)S.defects[S.sidx(li, j, k)];
     const double E_tot = pymax(P.E_diff[ia] + 0.1 * (double)n_bonds * P.E_b[ia], 0.0);
     DiffCtx c;
-    c.arr = exp(-defect_factor * E_tot / (P.kT * Tc));
+    c.arr = exp_nonpos(-defect_factor * E_tot / (P.kT * Tc));  // defect_factor >= 1, E_tot >= 0
     c.Tc = Tc;
     return c;
 }
