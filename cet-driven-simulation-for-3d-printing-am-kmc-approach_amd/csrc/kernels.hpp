@@ -634,11 +634,13 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
     // interface list) and k_interface has left their full EMPTY/DIFF category sum in ifc_val.
     for (int k = tid; k < Pk; k += 256) {
         double sum = 0.0; int cnt = 0;
+        int maybe_ifc = 1;      // 0: certainly no interface voxel (its EMPTY category can only hold a nucleation)
         if (k < L) {
             // state, membership flag, stored interface sum and temperature are requested together (one round trip)
             const int64_t t = S.tidx(li, j, k);
             const int st = S.state[S.sidx(li, j, k)];
             const bool listed = ifc_ready && S.ifc_in[t] != 0;
+            maybe_ifc = (!ifc_ready || listed) ? 1 : 0;
             const double v_ifc = S.ifc_val[t];
             const int c_ifc = S.ifc_cnt[t];
             const double Traw = S.T[t];
@@ -650,7 +652,7 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
                 eval_voxel(P, S, ktab, li, i, j, k, st, Traw, nb, emit);
             }
         }
-        hs[Pk + k] = sum; hf[Pk + k] = cnt > 0; leafcnt[k] = cnt;
+        hs[Pk + k] = sum; hf[Pk + k] = cnt > 0; leafcnt[k] = cnt | (maybe_ifc << 8);
     }
     __syncthreads();
     heap_build(hs, hf, Pk, tid);
@@ -658,21 +660,30 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
         double base = sh_base;
         const int k = heap_descend(hs, hf, Pk, base, r);
         long long rank = red[0];
-        if (c == CAT_DEP) for (int kk = 0; kk < k; ++kk) rank += leafcnt[kk];
+        if (c == CAT_DEP) for (int kk = 0; kk < k; ++kk) rank += leafcnt[kk] & 255;
         // slot scan (kmc_simulation.py:268-274 restricted to this voxel's slots)
-        const int st = S.state[S.sidx(li, j, k)];
-        double cum = base;
-        bool found = false;
         int p_type = -1, p_m = -1, p_atom = 0;
         double p_rate = 0.0;
-        auto nb = [&](int mm) -> int { return S.state[S.sidx(li + nbi_rt(mm), j + nbj_rt(mm), k + nbk_rt(mm))]; };
-        auto emit = [&](int cat, int type, double rate, int m, int atom) {
-            if (cat != c || found) return;
-            cum += rate;
-            p_type = type; p_m = m; p_atom = atom; p_rate = rate;   // remembers the last valid slot
-            if (cum >= r) found = true;
-        };
-        eval_voxel(P, S, ktab, li, i, j, k, st, S.T[S.tidx(li, j, k)], nb, emit);
+        const int lc = leafcnt[k];
+        if ((lc & 255) == 1 && (c == CAT_DEP || (c == CAT_EMPTY && !(lc >> 8)))) {
+            // a single event whose kind is known without looking again: the deposition of this voxel, or the nucleation
+            // of an empty voxel without W/Re/C neighbours; its rate is the leaf itself
+            p_type = (c == CAT_DEP) ? EV_DEP : EV_NUC;
+            p_atom = (c == CAT_DEP) ? 0 : 1;
+            p_rate = hs[Pk + k];
+        } else {
+            const int st = S.state[S.sidx(li, j, k)];
+            double cum = base;
+            bool found = false;
+            auto nb = [&](int mm) -> int { return S.state[S.sidx(li + nbi_rt(mm), j + nbj_rt(mm), k + nbk_rt(mm))]; };
+            auto emit = [&](int cat, int type, double rate, int m, int atom) {
+                if (cat != c || found) return;
+                cum += rate;
+                p_type = type; p_m = m; p_atom = atom; p_rate = rate;   // remembers the last valid slot
+                if (cum >= r) found = true;
+            };
+            eval_voxel(P, S, ktab, li, i, j, k, st, S.T[S.tidx(li, j, k)], nb, emit);
+        }
         cetkmc_event ev;
         ev.type = p_type;
         ev.pos[0] = i; ev.pos[1] = j; ev.pos[2] = k;
