@@ -1273,7 +1273,7 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
     C.PH = 1; while (C.PH < C.H) C.PH <<= 1;
     C.PT = 1; while (C.PT < 3 * C.H) C.PT <<= 1;
     const int D = C.nb * C.nb * C.nb;
-    const size_t shmem = (size_t)C.PT * C.PH * C.PH * 18;     // heap: 2*NL doubles + 2*NL flags
+    const size_t shmem = (size_t)C.PT * C.PH * C.PH * 19;     // heap: 2*NL doubles + 2*NL flags, NL leaf codes
     {
         size_t c1 = h->cap_steps, c2 = h->cap_steps, c3 = h->cap_steps, c4 = h->cap_steps, c5 = h->cap_steps;
         CHK(grow(&h->d_u_pick, &c1, (size_t)n));

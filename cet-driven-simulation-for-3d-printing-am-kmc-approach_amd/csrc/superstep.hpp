@@ -23,6 +23,9 @@ struct SuperCfg {
 struct DomPick {          // result of the tree descent of one box
     int32_t i, j, k, cat;  // cat < 0: idle box
     double base, r;
+    double rate;           // simple: the chosen leaf itself (its single event's rate)
+    int32_t simple, pad;   // 1: a single event whose kind is known without evaluating the voxel again (deposition, or the
+                           // nucleation of an empty voxel that is not an interface voxel)
 };
 
 // One wave per box: leaves = category sums of the window's voxels, LDS heap of NL = PT*PH*PH leaves, descent.
@@ -38,7 +41,8 @@ __global__ __launch_bounds__(64) void k_domain_pick(KParams P, const SlabView* _
     const int NL = C.PT * C.PH * C.PH;
     double* hs = reinterpret_cast<double*>(smem);             // [2*NL]
     uint8_t* hf = reinterpret_cast<uint8_t*>(hs + 2 * NL);    // [2*NL]
-    for (int q = lane; q < NL; q += 64) { hs[NL + q] = 0.0; hf[NL + q] = 0; }
+    uint8_t* lc = hf + 2 * NL;                                // [NL] leaf: event count | 128 if the voxel is a listed interface voxel
+    for (int q = lane; q < NL; q += 64) { hs[NL + q] = 0.0; hf[NL + q] = 0; lc[q] = 0; }
     __syncthreads();
     const int64_t g = C.step0 + ss->cur;
     const int sec = (int)(g & 7);
@@ -54,15 +58,19 @@ __global__ __launch_bounds__(64) void k_domain_pick(KParams P, const SlabView* _
         const int li = i - S.gi0 + 2;
         const int st = S.state[S.sidx(li, j, k)];
         const int64_t t = S.tidx(li, j, k);
+        // value, count and membership flag are requested together with the state
+        const double val = S.ifc_val[t];
+        const int n_ev = S.ifc_cnt[t];
+        const int listed = S.ifc_in[t] != 0;
         if (st >= 128 || st == 4) continue;
         const int c = (st == 0) ? CAT_EMPTY : CAT_DIFF;
         const int q = ((3 * ii + c) * C.PH + jj) * C.PH + kk;
-        hs[NL + q] = S.ifc_val[t]; hf[NL + q] = S.ifc_cnt[t] > 0;
+        hs[NL + q] = val; hf[NL + q] = n_ev > 0; lc[q] = (uint8_t)(n_ev | (listed << 7));
         if (st == 0 && i == L - 1) {
             const double rate = dep_rate(P, pymax(S.T[t], 1.0));
             if (finite_d(rate)) {
                 const int qd = ((3 * ii + CAT_DEP) * C.PH + jj) * C.PH + kk;
-                hs[NL + qd] = rate; hf[NL + qd] = 1;
+                hs[NL + qd] = rate; hf[NL + qd] = 1; lc[qd] = 1;
             }
         }
     }
@@ -77,7 +85,7 @@ __global__ __launch_bounds__(64) void k_domain_pick(KParams P, const SlabView* _
     }
     if (lane != 0) return;
     DomPick pk;
-    pk.i = pk.j = pk.k = 0; pk.cat = -1; pk.base = 0.0; pk.r = 0.0;
+    pk.i = pk.j = pk.k = 0; pk.cat = -1; pk.base = 0.0; pk.r = 0.0; pk.rate = 0.0; pk.simple = 0; pk.pad = 0;
     const double R = hs[1];
     if (hf[1] && !(R < 1e-25) && finite_d(R)) {
         const double r = counter_uniform(C.seed, (uint64_t)g, KEY_PICK | (uint64_t)d) * R;
@@ -92,6 +100,8 @@ __global__ __launch_bounds__(64) void k_domain_pick(KParams P, const SlabView* _
         const int b = q / (C.PH * C.PH);
         pk.i = i0 + b / 3; pk.cat = b % 3; pk.j = j0 + (q / C.PH) % C.PH; pk.k = k0 + q % C.PH;
         pk.base = base; pk.r = r;
+        pk.rate = hs[NL + q];
+        pk.simple = (lc[q] == 1 && pk.cat != CAT_DIFF) ? 1 : 0;     // one event, voxel not listed (or a deposition leaf)
     }
     picks[d] = pk;
 }
@@ -125,19 +135,25 @@ __global__ __launch_bounds__(64) void k_domain_slot_apply(KParams P, const SlabV
         for (int s = 0; s < nslabs; ++s) if (i >= slabs[s].gi0 && i < slabs[s].gi0 + slabs[s].nloc) sl = s;
         const SlabView& S = slabs[sl];
         const int li = i - S.gi0 + 2;
-        const int st = S.state[S.sidx(li, j, k)];
-        double cum = pk.base;
-        bool found = false;
         int p_type = -1, p_m = -1, p_atom = 0;
         double p_rate = 0.0;
-        auto nbs = [&](int mm) -> int { return S.state[S.sidx(li + nbi_rt(mm), j + nbj_rt(mm), k + nbk_rt(mm))]; };
-        auto emit = [&](int cat, int type, double rate, int m, int atom) {
-            if (cat != c || found) return;
-            cum += rate;
-            p_type = type; p_m = m; p_atom = atom; p_rate = rate;   // remembers the last valid slot
-            if (cum >= r) found = true;
-        };
-        eval_voxel(P, S, ktab, li, i, j, k, st, S.T[S.tidx(li, j, k)], nbs, emit);
+        if (pk.simple) {            // the deposition of this voxel / the nucleation of a bulk empty voxel: nothing to scan
+            p_type = (c == CAT_DEP) ? EV_DEP : EV_NUC;
+            p_atom = (c == CAT_DEP) ? 0 : 1;
+            p_rate = pk.rate;
+        } else {
+            const int st = S.state[S.sidx(li, j, k)];
+            double cum = pk.base;
+            bool found = false;
+            auto nbs = [&](int mm) -> int { return S.state[S.sidx(li + nbi_rt(mm), j + nbj_rt(mm), k + nbk_rt(mm))]; };
+            auto emit = [&](int cat, int type, double rate, int m, int atom) {
+                if (cat != c || found) return;
+                cum += rate;
+                p_type = type; p_m = m; p_atom = atom; p_rate = rate;   // remembers the last valid slot
+                if (cum >= r) found = true;
+            };
+            eval_voxel(P, S, ktab, li, i, j, k, st, S.T[S.tidx(li, j, k)], nbs, emit);
+        }
         ev.type = p_type;
         ev.pos[0] = i; ev.pos[1] = j; ev.pos[2] = k;
         ev.atom = p_atom; ev.rate = p_rate;
