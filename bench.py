@@ -5,19 +5,22 @@ lattice; achieved HBM GB/s).
   python bench.py --gpus 1 --steps K --warmup W          (N=1: config 3, 256^3, one MI355X)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
 
-A "step" is ONE exact KMC step (Mode A): full-lattice rate sweep (every candidate event's
-Arrhenius rate evaluated and reduced), cumulative-rate event pick, lattice update, plus the
-melt-pool temperature update every 20 steps.  `value` = candidate events evaluated+scanned per
-second (sum over the timed steps of len(events)) / time -- the reference's unit of work per
-sweep; the executed-event rate (= steps/s, one event per sweep exactly like the reference) is
-reported next to it and never conflated with it.
+A "step" is ONE exact KMC step (Mode A): full-lattice rate sweep (every candidate event's rate
+looked up / evaluated and reduced), cumulative-rate event pick, lattice update, plus the melt-pool
+temperature update, rate-table refresh and interface-list evaluation every 20 steps.
+`value` = EXECUTED events per second of that loop (= steps/s: one event per sweep, exactly like the
+reference).  The candidate-event rate (entries of get_event_rates' list per second), the exact
+incremental loop and Mode B (several events per sweep) are reported beside it under their own names.
 
-N>1 is weak scaling: L = 256/320/408/512 for 1/2/4/8 GPUs (about 1.68e7 voxels per GPU),
-axis-0 slabs, RCCL all-gathers of the block sums and of the chosen event every step, T halo
-send/recv after every thermal update.  torch is imported only for the multi-process
-rendezvous/barrier; the data path is HIP + RCCL inside libcetkmc_hip.so.
+`--gpus N` runs BASELINE.json's configurations: N=1 config 3 (256^3), N=2/4 config 4 (the SAME 256^3
+lattice in 2/4 axis-0 slabs: strong scaling), N=8 config 5 (512^3, impurity_c=0.2, defect mask refreshed
+every 200 steps).  `--scaling weak` keeps the per-GPU voxel count fixed instead (L = 256/320/408/512).
+Across ranks: RCCL all-gathers of the block sums and of the chosen event every step, T halo send/recv after
+every thermal update.  torch is imported only for the multi-process rendezvous/barrier; the data path is HIP
++ RCCL inside libcetkmc_hip.so.
 """
 import argparse
+import glob
 import json
 import os
 import random
@@ -32,10 +35,12 @@ for p in (PKG, ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-L_FOR_GPUS = {1: 256, 2: 320, 4: 408, 8: 512}
+L_BASELINE = {1: 256, 2: 256, 4: 256, 8: 512}      # BASELINE.json configs 3, 4, 4, 5
+L_WEAK = {1: 256, 2: 320, 4: 408, 8: 512}          # ~1.68e7 voxels per GPU
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-B_ALG_SWEEP = 10.0             # bytes/voxel/sweep: census class u16 + T f64, each read once
+B_ALG_SWEEP = 9.0              # bytes/voxel/sweep: census class u8 + rate-table entry f64, each read once
 IMPURITY_C, DEFECT_FRACTION, SEED = 0.2, 3e-3, 42
+DEFECT_REFRESH_EVERY = 200     # kmc_simulation.py:335-338 (METRIC_UPDATE_STEP)
 
 
 def streams(n, seed):
@@ -58,6 +63,7 @@ def cpu_baseline(L, fields, n_gpu_events, budget_s=15.0):
     n_max = len(n_gpu_events)
     n_threads = max(1, min(16, os.cpu_count() or 1))          # a 1-GPU box's CPU share
     legs = {"single": [1, 0, 0.0], "multi": [n_threads, 0, 0.0]}     # threads, steps, seconds
+    np_pos = 0
     for leg in ("single", "multi"):
         oracle.set_threads(legs[leg][0])
         while done < n_max:
@@ -67,10 +73,10 @@ def cpu_baseline(L, fields, n_gpu_events, budget_s=15.0):
             t0 = time.perf_counter()
             # rng_mode 1 consumes only orientation draws; replay the cursor from the GPU log
             res = lat.run_steps(done, n, DEFECT_FRACTION, u_pick[done:done + n], u_def[done:done + n],
-                                u_np[cpu_baseline.np_pos:], rng_mode=1, seed=SEED, thermal_mode=2, q_planes=q)
+                                u_np[np_pos:], rng_mode=1, seed=SEED, thermal_mode=2, q_planes=q)
             legs[leg][2] += time.perf_counter() - t0
             legs[leg][1] += res["done"]
-            cpu_baseline.np_pos += res["np_used"]
+            np_pos += res["np_used"]
             ev_all.append(res["events"])
             nev_all.append(res["n_events"])
             done += res["done"]
@@ -82,26 +88,25 @@ def cpu_baseline(L, fields, n_gpu_events, budget_s=15.0):
     return dict(steps=done, events=ev, n_events=nev, legs=legs)
 
 
-cpu_baseline.np_pos = 0
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--L", type=int, default=0)
+    ap.add_argument("--scaling", choices=["baseline", "weak"], default="baseline",
+                    help="baseline: BASELINE.json configs (N=2/4: 256^3 split, N=8: 512^3); weak: ~1.68e7 voxels per GPU")
+    ap.add_argument("--config5", action="store_true", help="force config 5's workload (defect refresh every 200 steps) at any N / L")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-incremental", action="store_true", help="skip the extra exact-incremental-mode run")
     ap.add_argument("--no-mode-b", action="store_true", help="skip the extra Mode B (super-step) run")
     ap.add_argument("--no-phases", action="store_true", help="skip the extra per-phase timing run")
+    ap.add_argument("--no-recompute", action="store_true", help="skip the extra run of the recompute sweep variant")
     ap.add_argument("--transport", choices=["rccl", "host"], default="rccl",
                     help="N > 1: RCCL over xGMI (default) or the host-relay transport (ranks may share one GPU; rehearsal only)")
     ap.add_argument("--set-option", action="append", default=[], metavar="KEY=INT", help="cetkmc_set_option before the run")
-    ap.add_argument("--overlap-interface", type=int, default=-1,
-                    help="speculative interface evaluation of the next step during select/collectives: 1 on, 0 off (default: engine default = off)")
     ap.add_argument("--extras-multi", action="store_true",
-                    help="also run the exact-incremental extra at N > 1 (default: N = 1 only, the scaling runs time the full-sweep loop alone)")
+                    help="also run the phase / incremental extras at N > 1 (default: N = 1 only; Mode B always runs)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-process code path (gloo rendezvous + RCCL communicator) even with one rank")
@@ -113,9 +118,18 @@ def main():
     N = a.gpus
     if world != N and world > 1:
         raise SystemExit(f"--gpus {N} but WORLD_SIZE={world}")
-    L = a.L or L_FOR_GPUS.get(N, 256)
+    L = a.L or (L_BASELINE if a.scaling == "baseline" else L_WEAK).get(N, 256)
     if L % N:
         raise SystemExit(f"L={L} not divisible by {N} ranks")
+    config5 = a.config5 or (a.scaling == "baseline" and N == 8 and not a.L)
+    if config5:
+        cfg_name, scaling = "config5", "weak"          # 8x the voxels of config 3 on 8 GPUs
+    elif N == 1:
+        cfg_name, scaling = "config3", "weak"
+    elif a.scaling == "baseline" and not a.L:
+        cfg_name, scaling = "config4", "strong"        # the 256^3 lattice of config 3, split
+    else:
+        cfg_name, scaling = "config3-weak", "weak"
 
     # Libraries chat on stdout (gloo's "[Gloo] Rank ..." line, RCCL's version banner under NCCL_DEBUG): keep fd 1 for
     # the ONE JSON line -- everything else goes to stderr until the result is printed.
@@ -148,11 +162,24 @@ def main():
     else:
         eng = cetkmc.Engine(L, impurity_c=IMPURITY_C, device=0)
 
-    if a.overlap_interface >= 0:
-        eng.set_option("overlap_interface", a.overlap_interface)
-    for kv in a.set_option:                       # engine options for A/B runs, e.g. --set-option fused_reduce=0
+    for kv in a.set_option:                       # engine options for A/B runs, e.g. --set-option sweep_variant=2
         k, v = kv.split("=")
         eng.set_option(k, int(v))
+
+    def allreduce(x, op):
+        if dist is None:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=getattr(dist.ReduceOp, op))
+        return float(t[0])
+
+    def rank_counts(n_mine):
+        if dist is None:
+            return [int(n_mine)]
+        box = [None] * N
+        dist.all_gather_object(box, int(n_mine))
+        return box
 
     # ---- synthetic input, resident in HBM before anything is timed -----------------------
     a0, a1 = max(0, eng.i0 - 2), min(L, eng.i1 + 2)
@@ -166,11 +193,47 @@ def main():
         return dict(step0=step0, n=n, u_pick=u_pick[step0:], u_def=u_def[step0:], u_np=u_np,
                     q=synthetic.laser_planes(L, step0, n))
 
-    def run(step0, n, profile=False, logs=False, prep=None, incremental=False):
+    refresh_ms = []
+
+    def refresh_defects():
+        """config 5: defects.track_defects after every step with step % 200 == 0 (kmc_simulation.py:335-338), without
+        moving the lattice: carbon sites (index + T) of the owned planes -> host draws in global row-major site
+        order -> flagged indices back.  Every rank draws the same seeded stream and uses its own slice."""
+        import defects as defects_mod
+        t0 = time.perf_counter()
+        defects_mod.refresh_defects_device(eng, rank_counts=rank_counts, rank=rank)
+        eng.sync()
+        refresh_ms.append(1e3 * (time.perf_counter() - t0))
+
+    def run(step0, n, profile=False, prep=None, incremental=False):
+        """Steps step0 .. step0+n-1 as device batches; config 5 splits the batches after every step % 200 == 0."""
         b = prep or prepare(step0, n)
-        return eng.run_steps(step0, n, DEFECT_FRACTION, b["u_pick"], b["u_def"], b["u_np"][run.np_pos:],
-                             rng_mode=1, seed=SEED, thermal_mode=2, q_planes=b["q"], use_latent=True,
-                             profile=profile, want_logs=True, incremental=incremental)
+        out, s = None, step0
+        while s < step0 + n:
+            e = step0 + n
+            if config5:
+                nxt = -(-s // DEFECT_REFRESH_EVERY) * DEFECT_REFRESH_EVERY         # first step >= s that is a multiple of 200
+                e = min(e, nxt + 1)
+            o0 = s - step0
+            q_lo = sum(1 for g in range(step0, s) if g % 20 == 0)
+            r = eng.run_steps(s, e - s, DEFECT_FRACTION, b["u_pick"][o0:], b["u_def"][o0:], b["u_np"][run.np_pos:],
+                              rng_mode=1, seed=SEED, thermal_mode=2, q_planes=b["q"][q_lo:], use_latent=True,
+                              profile=profile, want_logs=True, incremental=incremental)
+            run.np_pos += r["np_used"]
+            if out is None:
+                out = r
+            else:
+                for k in ("done", "sweep_ms_total", "sweep_launches", "wall_ms", "full_sweeps", "np_used"):
+                    out[k] += r[k]
+                out["status"] = r["status"]
+                for k in ("n_events", "totals", "events"):
+                    out[k] = np.concatenate([out[k], r[k]])
+            if r["done"] < e - s:
+                break
+            if config5 and (e - 1) % DEFECT_REFRESH_EVERY == 0:
+                refresh_defects()
+            s = e
+        return out
     run.np_pos = 0
 
     def barrier():
@@ -181,10 +244,9 @@ def main():
     # ---- parity sample + CPU baseline (rank 0, N=1): GPU and oracle run the same first steps
     step = 0
     base = None
-    if N == 1 and not a.no_cpu_baseline:
+    if N == 1 and not a.no_cpu_baseline and not config5:
         n_chk = 40
-        r = run(0, n_chk, logs=True)
-        run.np_pos += r["np_used"]
+        r = run(0, n_chk)
         step = r["done"]
         base = cpu_baseline(L, (state, theta, phi, T, defects), r["n_events"], a.cpu_budget)
         k = base["steps"]
@@ -193,60 +255,77 @@ def main():
         base["parity"] = bool(same)
         if not same:
             print("WARNING: GPU and CPU oracle disagree on the first steps", file=sys.stderr)
-        del state, theta, phi, T, defects
+    del state, theta, phi, T, defects
 
     # ---- warmup, then EXACTLY K timed steps ------------------------------------------------
     if a.warmup:
         r = run(step, a.warmup)
-        run.np_pos += r["np_used"]
         step += r["done"]
     timed_inputs = prepare(step, a.steps)
+    # short runs (the driver's 20 steps): hipEvents around EVERY sweep launch; long runs: every 8th (a record costs ~5 us)
+    prof_mode = 1 if a.steps <= 64 else 3
     barrier()
     t0 = time.perf_counter()
-    r = run(step, a.steps, profile=3, prep=timed_inputs)      # sweep kernel timed by hipEvents on every 8th launch
+    r = run(step, a.steps, profile=prof_mode, prep=timed_inputs)
     barrier()
-    dt = time.perf_counter() - t0
+    dt = allreduce(time.perf_counter() - t0, "MAX")
     assert r["done"] == a.steps and r["status"] == 0, r
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
+    step += a.steps
 
     # ---- after the timed region: per-phase device time (hipEvents at every phase boundary, cetkmc_get_counters)
-    run.np_pos += r["np_used"]
     phases = None
     if not a.no_phases and (N == 1 or a.extras_multi):
         n_ph = min(200, a.steps)
-        ph_inputs = prepare(step + a.steps, n_ph)
+        ph_inputs = prepare(step, n_ph)
         eng.counters(reset=True)
-        rp = run(step + a.steps, n_ph, profile=2, prep=ph_inputs)
+        rp = run(step, n_ph, profile=2, prep=ph_inputs)
         c = eng.counters()
-        run.np_pos += rp["np_used"]
+        step += rp["done"]
         if rp["done"] == n_ph and c["profiled_steps"] == n_ph:
             phases = {k[3:] + "_us_per_step": 1e3 * c[k] / n_ph for k in ("ms_thermal", "ms_interface", "ms_sweep", "ms_reduce",
                                                                            "ms_select_apply")}
+            phases["table_interface_us_per_step"] = phases.pop("interface_us_per_step")
             phases.update(steps=n_ph, device_us_per_step=1e3 * rp["wall_ms"] / n_ph,
-                          alg_bytes_per_step=(c["alg_bytes_sweep"] + c["alg_bytes_thermal"]) / n_ph,
+                          thermal_updates=c["thermal_updates"], table_updates=c["table_updates"],
+                          interface_launches=c["interface_launches"],
+                          alg_bytes_per_step=(c["alg_bytes_sweep"] + c["alg_bytes_thermal"] + c["alg_bytes_table"]) / n_ph,
                           note="full-sweep loop, hipEvents at every phase boundary (slower than the timed run by the event "
-                               "records); thermal averaged over its 1-in-20 cadence")
+                               "records); thermal / rate table / interface list averaged over their 1-in-20 cadence")
+
+    # ---- the recompute variant of the sweep kernel (nucleation rates evaluated in every sweep instead of looked up)
+    recompute = None
+    if not a.no_recompute and N == 1:
+        n_rc = min(200, a.steps)
+        rc_inputs = prepare(step, n_rc)
+        eng.set_option("sweep_variant", 2)
+        eng.sync()
+        t3 = time.perf_counter()
+        rr = run(step, n_rc, profile=1, prep=rc_inputs)
+        eng.sync()
+        dtr = time.perf_counter() - t3
+        eng.set_option("sweep_variant", 1)
+        step += rr["done"]
+        if rr["done"] == n_rc and rr["sweep_launches"]:
+            ms = rr["sweep_ms_total"] / rr["sweep_launches"]
+            ach = B_ALG_SWEEP * (eng.i1 - eng.i0) * L * L / (ms * 1e-3) / 1e9
+            recompute = {"kernel": "k_sweep_stream<recompute>", "avg_launch_ms": ms, "launches_timed": int(rr["sweep_launches"]),
+                         "achieved": ach, "frac": ach / HBM_PEAK_GBS, "steps_per_s": n_rc / dtr,
+                         "note": "sweep_variant 2: streams T instead of the rate table and evaluates the nucleation rate of "
+                                 "every bulk empty voxel in the sweep (same bits; tests/test_gpu_parity.py::"
+                                 "test_sweep_variants_bit_identical); steps_per_s includes the hipEvent records"}
 
     # ---- the same loop in exact incremental mode (reported beside `value`, never as it)
     inc = None
     if not a.no_incremental and (N == 1 or a.extras_multi):
-        inc_inputs = prepare(step + 2 * a.steps, a.steps)
+        inc_inputs = prepare(step, a.steps)
         barrier()
         t1 = time.perf_counter()
-        ri = run(step + 2 * a.steps, a.steps, prep=inc_inputs, incremental=True)
+        ri = run(step, a.steps, prep=inc_inputs, incremental=True)
         barrier()
-        dti = time.perf_counter() - t1
-        if dist is not None:
-            import torch
-            t = torch.tensor([dti], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dti = float(t[0])
+        dti = allreduce(time.perf_counter() - t1, "MAX")
+        step += ri["done"]
         if ri["done"] == a.steps:
-            inc = {"steps_per_s": a.steps / dti, "ms_per_step": 1e3 * dti / a.steps, "full_sweeps": ri["full_sweeps"],
+            inc = {"steps_per_s": a.steps / dti, "ms_per_step": 1e3 * dti / a.steps, "full_sweeps": int(ri["full_sweeps"]),
                    "steps": a.steps,
                    "note": "cetkmc_run_steps incremental=1 on the following K steps: between temperature updates only the "
                            "rows the previous event made stale are re-evaluated; bit-identical to full sweeps "
@@ -254,20 +333,22 @@ def main():
 
     # ---- Mode B (super-steps over 8^3 boxes; not the reference's trajectory, own CPU comparator): executed events/s
     mode_b = None
-    if N == 1 and not a.no_mode_b and L % 8 == 0:
-        sb, nb_steps = step + 3 * a.steps, 40
-        qb = synthetic.laser_planes(L, sb, nb_steps)
-        eng.sync()
+    if not a.no_mode_b and L % 8 == 0 and (L // N) % 8 == 0:
+        nb_steps = 40
+        qb = synthetic.laser_planes(L, step, nb_steps)
+        barrier()
         t2 = time.perf_counter()
-        rb = eng.run_supersteps(sb, nb_steps, 8, DEFECT_FRACTION, seed=SEED, thermal_mode=2, q_planes=qb)
-        eng.sync()
-        dtb = time.perf_counter() - t2
+        rb = eng.run_supersteps(step, nb_steps, 8, DEFECT_FRACTION, seed=SEED, thermal_mode=2, q_planes=qb)
+        barrier()
+        dtb = allreduce(time.perf_counter() - t2, "MAX")
+        n_exec = allreduce(float(rb["n_exec"].sum()), "SUM")          # every rank counts the events of its own boxes
         if rb["done"] == nb_steps:
-            mode_b = {"executed_events_per_s": float(rb["n_exec"].sum()) / dtb, "ms_per_superstep": 1e3 * dtb / nb_steps,
-                      "events_per_superstep": float(rb["n_exec"].mean()), "boxes": rb["domains"], "supersteps": nb_steps,
+            mode_b = {"executed_events_per_s": n_exec / dtb, "ms_per_superstep": 1e3 * dtb / nb_steps,
+                      "events_per_superstep": n_exec / nb_steps, "boxes": (L // 8) ** 3, "supersteps": nb_steps,
                       "note": "cetkmc_run_supersteps box=8 on the lattice left by the runs above: one full rate sweep per "
-                              "super-step, every box executes <= 1 event from its active octant; bit-identical to "
-                              "oracle orc_run_supersteps (tests/test_gpu_mode_b.py); not part of `value`"}
+                              "super-step, every box executes <= 1 event from its active octant (boxes sharded with the "
+                              "slabs; boundary-layer events exchanged with the neighbour ranks every super-step); "
+                              "bit-identical to oracle orc_run_supersteps (tests/test_gpu_mode_b.py); not part of `value`"}
 
     cand = float(np.sum(r["n_events"].astype(np.float64)))     # identical on every rank (global counts)
     steps_per_s = a.steps / dt
@@ -275,7 +356,7 @@ def main():
     n_own = (eng.i1 - eng.i0) * L * L
     achieved = B_ALG_SWEEP * n_own / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
     traffic, traffic_src = None, None
-    for summary_path in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_summary.json")), reverse=True):
+    for summary_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")), reverse=True):
         try:
             kk = json.load(open(summary_path))["kernels"]["k_sweep_stream"]
             if N == 1 and L == 256 and "hbm_bytes_per_launch" in kk:
@@ -283,24 +364,38 @@ def main():
                 break
         except Exception:
             pass
+    workloads = {
+        "config3": f"config 3: {L}^3 voxel lattice, one MI355X",
+        "config4": f"config 4: the {L}^3 lattice of config 3 split into {N} axis-0 slabs, one rank per MI355X (strong scaling)",
+        "config5": f"config 5: {L}^3 voxel lattice in {N} axis-0 slab(s), impurity_c={IMPURITY_C}, defects.track_defects "
+                   f"refreshed after every step % {DEFECT_REFRESH_EVERY} == 0",
+        "config3-weak": f"config 3 workload at {L}^3 in {N} axis-0 slabs (~1.68e7 voxels per GPU, --scaling weak)",
+    }
     out = {
-        "metric": "kmc_events_per_sec", "value": cand / dt, "unit": "events/s",
+        "metric": "kmc_events_per_sec", "value": steps_per_s, "unit": "executed events/s",
         "n_gpus": N, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {
-            "workload": f"config3: {L}^3 voxel lattice ({N} axis-0 slab(s)), k<L/4 pre-filled W/Re/C, moving Gaussian "
-                        "melt-pool T-field (update_temperature every 20 steps), exact Mode A: 1 executed event per "
-                        "full rate sweep",
-            "L": L, "impurity_c": IMPURITY_C, "defect_fraction": DEFECT_FRACTION, "rng_mode": "counter",
-            "event_definition": "value counts CANDIDATE events (entries of get_event_rates' list: rates evaluated, "
-                                "reduced and scanned per sweep); executed events/s = steps_per_s",
+            "workload": workloads[cfg_name] + "; k<L/4 pre-filled W/Re/C, moving Gaussian melt-pool T-field "
+                        "(update_temperature every 20 steps), exact Mode A: 1 executed event per full rate sweep",
+            "baseline_config": cfg_name, "L": L, "impurity_c": IMPURITY_C, "defect_fraction": DEFECT_FRACTION,
+            "rng_mode": "counter", "transport": a.transport if N > 1 else "none",
+            "event_definition": "value = EXECUTED events/s of the exact loop (one per sweep, = steps/s); "
+                                "candidate_events_per_s = entries of get_event_rates' list evaluated, reduced and scanned per "
+                                "second (round 1 reported that number as value)",
         },
-        "steps_per_s": steps_per_s, "executed_events_per_s": steps_per_s,
+        "steps_per_s": steps_per_s,
+        "executed_events_per_s_mode_a": steps_per_s,
+        "executed_events_per_s_incremental": inc["steps_per_s"] if inc else None,
+        "executed_events_per_s_mode_b": mode_b["executed_events_per_s"] if mode_b else None,
+        "candidate_events_per_s": cand / dt,
         "candidate_events_per_step": cand / a.steps, "voxel_updates_per_s": float(L) ** 3 * steps_per_s,
         "device_ms_per_step": r["wall_ms"] / a.steps,
-        "roofline": {"bound": "hbm", "kernel": "k_sweep_stream", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": "k_sweep_stream<table>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "avg_launch_ms": sweep_ms, "launches_timed": int(r["sweep_launches"]),   # every 8th launch of the timed region
+                     "traffic_measured_in_run": False,
+                     "avg_launch_ms": sweep_ms, "launches_timed": int(r["sweep_launches"]),
+                     "launches_in_timed_region": int(r["full_sweeps"]),
                      "alg_bytes_per_voxel": B_ALG_SWEEP, "voxels_per_launch": n_own,
                      # BASELINE.md section 4 / SURVEY 8(d) pre-build accounting: 26.8 B per voxel per step (state u8 + T +
                      # theta + phi f64 + defects u8 streamed every sweep, thermal 16 B / 20) x steps/s.  The build does
@@ -312,20 +407,28 @@ def main():
     }
     if base is not None:
         nev = base["n_events"].astype(np.float64)
-        (t1, s1, sec1), (tm, sm, secm) = base["legs"]["single"], base["legs"]["multi"]
-        leg = ("multi", tm, sm, secm, float(nev[s1:s1 + sm].sum())) if sm > 0 else ("single", t1, s1, sec1, float(nev[:s1].sum()))
+        (t1c, s1, sec1), (tm, sm, secm) = base["legs"]["single"], base["legs"]["multi"]
+        multi = sm > 0
         out["cpu_baseline"] = {
-            "value": leg[4] / leg[3], "unit": "events/s", "cores": leg[1], "kind": "port",
-            "sample": f"steps {s1}..{s1 + sm} of the same {L}^3 workload on the C oracle with its row/thermal loops on "
-                      f"{leg[1]} host threads ({leg[3]:.1f} s, incl. thermal updates)" if sm > 0 else
+            "value": (sm / secm) if multi else (s1 / sec1), "unit": "executed events/s", "cores": tm if multi else t1c, "kind": "port",
+            "sample": (f"steps {s1}..{s1 + sm} of the same {L}^3 workload on the C oracle with its row/thermal loops on "
+                       f"{tm} host threads ({secm:.1f} s, incl. thermal updates)") if multi else
                       f"first {s1} steps of the same {L}^3 workload on the C oracle, 1 thread ({sec1:.1f} s)",
-            "steps_per_s": leg[2] / leg[3],
-            "single_core": {"value": float(nev[:s1].sum()) / sec1 if s1 else None, "steps_per_s": s1 / sec1 if s1 else None,
+            "candidate_events_per_s": (float(nev[s1:s1 + sm].sum()) / secm) if multi else (float(nev[:s1].sum()) / sec1),
+            "single_core": {"value": s1 / sec1 if s1 else None, "unit": "executed events/s",
+                            "candidate_events_per_s": float(nev[:s1].sum()) / sec1 if s1 else None,
                             "cores": 1, "sample": f"first {s1} steps, scalar port ({sec1:.1f} s)"},
             "host_cores_available": os.cpu_count(), "parity_first_steps": base["parity"],
         }
+    if config5:
+        out["defect_refresh"] = {"every_steps": DEFECT_REFRESH_EVERY, "calls": len(refresh_ms),
+                                 "ms_per_call": float(np.mean(refresh_ms)) if refresh_ms else None,
+                                 "note": "gather of the carbon sites + host Bernoulli draws + sparse mask upload; inside the timed "
+                                         "region whenever a timed step is a multiple of 200"}
     if phases is not None:
         out["phases"] = phases
+    if recompute is not None:
+        out["sweep_recompute"] = recompute
     if inc is not None:
         out["incremental_exact"] = inc
     if mode_b is not None:

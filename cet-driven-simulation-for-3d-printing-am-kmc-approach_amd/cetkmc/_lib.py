@@ -1,5 +1,6 @@
 """Loader + ctypes prototypes for include/cetkmc.h."""
 import ctypes as C
+import glob
 import os
 import subprocess
 
@@ -7,7 +8,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 INCLUDE = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include")
 SO_PATH = os.path.join(CSRC, "libcetkmc_hip.so")
-SOURCES = [os.path.join(CSRC, f) for f in ("cetkmc_hip.hip", "kernels.hpp", "voxel.hpp", "cluster.hpp")] + [os.path.join(INCLUDE, "cetkmc.h")]
+
+
+def sources():
+    """Every file the library is compiled from: csrc/*.hip, csrc/*.hpp, include/*.h (globbed, so that a new header
+    cannot be forgotten by the staleness check)."""
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp")) +
+                  glob.glob(os.path.join(INCLUDE, "*.h")))
+
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                "-fno-fast-math", "-I/opt/rocm/include"]
@@ -55,7 +63,8 @@ class SuperArgs(C.Structure):
 class Counters(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("steps", "sweeps", "incremental_steps", "thermal_updates", "supersteps", "bytes_h2d",
                                          "bytes_d2h", "alg_bytes_sweep", "alg_bytes_thermal", "profiled_steps")] + \
-               [(n, C.c_double) for n in ("ms_thermal", "ms_interface", "ms_sweep", "ms_dirty_rows", "ms_reduce", "ms_select_apply")]
+               [(n, C.c_double) for n in ("ms_thermal", "ms_interface", "ms_sweep", "ms_dirty_rows", "ms_reduce", "ms_select_apply")] + \
+               [(n, C.c_int64) for n in ("alg_bytes_table", "table_updates", "interface_launches")]
 
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
@@ -121,11 +130,18 @@ PROTOTYPES = {
 }
 
 
+LAST_BUILD = None      # "compiled" | "reused" after build_library()
+
+
 def build_library(force=False, verbose=False):
-    """hipcc cross-compiles for gfx950 without a GPU; the .so stays in-tree (csrc/)."""
-    newest = max(os.path.getmtime(s) for s in SOURCES)
+    """hipcc cross-compiles for gfx950 without a GPU; the .so stays in-tree (csrc/).  Recompiles when any source
+    (sources()) is newer than the library."""
+    global LAST_BUILD
+    newest = max(os.path.getmtime(s) for s in sources())
     if not force and os.path.exists(SO_PATH) and os.path.getmtime(SO_PATH) >= newest:
+        LAST_BUILD = "reused"
         return SO_PATH
+    LAST_BUILD = "compiled"
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, "cetkmc_hip.hip"), "-o", SO_PATH, "-ldl"]
     if verbose:

@@ -282,7 +282,10 @@ class Engine:
         a.step0, a.n_steps, a.box, a.defect_fraction, a.seed = int(step0), int(n), int(box), float(defect_fraction), int(seed)
         a.thermal_mode, a.thermal_dt = int(thermal_mode), float(thermal_dt)
         a.q_planes, a.n_q, a.use_latent = _dptr(q), (0 if q is None else q.shape[0]), int(bool(use_latent))
-        D = (self.L // int(box)) ** 3 if box and self.L % int(box) == 0 else 1
+        # boxes of this handle: the box layers of its owned planes (across ranks every rank runs its own boxes and logs
+        # their events / executed counts; global box order = rank order)
+        nbx = self.L // int(box) if box and self.L % int(box) == 0 else 1
+        D = max(1, (self.i1 - self.i0) // int(box)) * nbx * nbx if box and self.L % int(box) == 0 else 1
         res = RunResult()
         totals = np.zeros(n + 1, np.float64)
         n_exec = np.zeros(max(n, 1), np.int64)

@@ -96,10 +96,6 @@ struct Handle {
     int L = 0, Pk = 1, PB = 1, RJ = 0, pitchS = 0, pitchT = 0, pitchC = 0;
     int dev = 0;
     hipStream_t stream = nullptr, stream2 = nullptr;
-    hipEvent_t ev_swept = nullptr, ev_ifc = nullptr;
-    int overlap_ifc = 0;       // speculative k_interface of step s+1 overlapped with reduce/select of step s: costs ~18 us per
-                               // step on one GPU (event syncs + touched-voxel re-evaluation); candidate for N > 1, where it
-                               // would run inside the two collectives' latency (bench.py --overlap-interface 1), unmeasured
     std::vector<Slab> slabs;
     SlabView* d_views[2] = {nullptr, nullptr};   // per T-buffer parity
     int cur = 0;                                 // current T buffer
@@ -124,13 +120,16 @@ struct Handle {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
     bool swept = false;
-    int sweep_variant = 1;
+    int sweep_variant = 1;     // 0 simple, 1 streaming + rate table (default), 2 streaming, nucleation rates recomputed per sweep
+    bool table_fresh = false;  // vval / dep_val match the current T and parameters (k_rate_table)
+    bool ifc_fresh = false;    // vval / ifc_cnt of every listed voxel match the current lattice, T, defects and parameters
+    int ifc_every_step = 0;    // 1: k_interface before every full sweep (round-1 behaviour, A/B); 0: only when stale --
+                               // between temperature updates the apply kernel re-evaluates the <= 30 listed voxels an event touches
     int thermal_variant = 1;   // 1 = plane-marching LDS kernel, 0 = one thread per voxel
     int therm_ni = THERM_NI;   // planes per block of the marching kernel
     int ifc_blocks = 64;       // grid of k_interface (grid-stride over the device-side list length)
     int ifc_block = 256;
     size_t shmem_stream = 0;
-    int stream_tj = SWEEP_TJ;  // rows per block of the streaming sweep: 8, or 4 when the 8-row LDS ring would exceed ~40 KB
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // grain clustering (cetkmc_cluster): results kept until the next call
     int *d_cc_parent = nullptr, *d_cc_roots = nullptr, *d_cc_cid = nullptr, *d_cc_labels = nullptr, *d_cc_stats = nullptr, *d_cc_n = nullptr;
@@ -217,21 +216,12 @@ int create_common(const cetkmc_params* p, int L, const std::vector<std::pair<int
     h->pitchT = round_up(L, 2);
     if (const char* e = getenv("CETKMC_TPAD")) h->pitchT += 2 * atoi(e);   // experiment: row padding (doubles/2)
     if (const char* e = getenv("CETKMC_IFC_BLOCK")) h->ifc_block = atoi(e);
-    h->pitchC = round_up(KOFFC + L + 8, 8);
-    auto stream_lds = [&](int tj) { return (size_t)((5 * (tj + 4) * h->pitchC * 2 + 15) & ~15) + (226 + tj * 3 * STREAM_MAXCH) * sizeof(double); };
-    h->stream_tj = (stream_lds(8) <= 40 * 1024) ? 8 : 4;
-    if (const char* e = getenv("CETKMC_STREAM_TJ")) h->stream_tj = (atoi(e) == 4) ? 4 : 8;
-    h->shmem_stream = stream_lds(h->stream_tj);
-    if (h->shmem_stream > 160 * 1024) { delete h; return fail("L too large for the LDS ring"); }
-    HIPCHK(hipFuncSetAttribute((const void*)k_sweep_stream<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds(8)));
-    HIPCHK(hipFuncSetAttribute((const void*)k_sweep_stream<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds(4)));
-    HIPCHK(hipFuncSetAttribute((const void*)k_sweep_stream<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds(8)));
-    HIPCHK(hipFuncSetAttribute((const void*)k_sweep_stream<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds(4)));
+    h->pitchC = round_up(KOFFC + L + 12, 16);
+    h->shmem_stream = (size_t)STREAM_SLOTS * (SWEEP_TJ + 4) * h->pitchC;
+    if (h->shmem_stream > 64 * 1024 || (SWEEP_TJ + 4) * h->pitchC > 16 * 256 * STREAM_MAXPF) { delete h; return fail("L too large for the LDS ring"); }
     h->dev = dev; h->G = G; h->my_first = my_first;
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_swept, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_ifc, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&h->ev0));
     HIPCHK(hipEventCreate(&h->ev1));
     h->own_i0 = ranges.front().first;
@@ -243,8 +233,8 @@ int create_common(const cetkmc_params* p, int L, const std::vector<std::pair<int
         s.nS = (size_t)(r.second + 4) * h->RJ * h->pitchS;
         s.nT = (size_t)(r.second + 4) * L * h->pitchT;
         s.nC = (size_t)(r.second + 4) * h->RJ * h->pitchC;
-        HIPCHK(hipMalloc((void**)&s.v.cls, s.nC * sizeof(uint16_t)));
-        HIPCHK(hipMemsetAsync(s.v.cls, 0, s.nC * sizeof(uint16_t), h->stream));
+        HIPCHK(hipMalloc((void**)&s.v.cls, s.nC));
+        HIPCHK(hipMemsetAsync(s.v.cls, 0, s.nC, h->stream));
         HIPCHK(hipMalloc((void**)&s.v.state, s.nS));
         HIPCHK(hipMalloc((void**)&s.v.defects, s.nS));
         HIPCHK(hipMalloc((void**)&s.prev, s.nS));
@@ -263,7 +253,7 @@ int create_common(const cetkmc_params* p, int L, const std::vector<std::pair<int
         HIPCHK(hipMemsetAsync(s.v.theta, 0, s.nT * sizeof(double), h->stream));
         HIPCHK(hipMemsetAsync(s.v.phi, 0, s.nT * sizeof(double), h->stream));
         HIPCHK(hipMalloc((void**)&s.v.ovec, 3 * s.nT * sizeof(double)));
-        HIPCHK(hipMalloc((void**)&s.v.ifc_val, s.nT * sizeof(double)));
+        HIPCHK(hipMalloc((void**)&s.v.vval, s.nT * sizeof(double)));
         HIPCHK(hipMalloc((void**)&s.v.dep_val, (size_t)L * h->pitchT * sizeof(double)));
         HIPCHK(hipMemsetAsync(s.v.dep_val, 0, (size_t)L * h->pitchT * sizeof(double), h->stream));
         HIPCHK(hipMalloc((void**)&s.v.ifc_cnt, s.nT));
@@ -272,7 +262,7 @@ int create_common(const cetkmc_params* p, int L, const std::vector<std::pair<int
         HIPCHK(hipMemsetAsync(s.v.ifc_code, 0xFF, s.nT * sizeof(uint32_t), h->stream));
         HIPCHK(hipMalloc((void**)&s.v.ifc_list, (size_t)r.second * L * L * sizeof(uint32_t)));
         HIPCHK(hipMalloc((void**)&s.v.ifc_n, sizeof(int)));
-        HIPCHK(hipMemsetAsync(s.v.ifc_val, 0, s.nT * sizeof(double), h->stream));
+        HIPCHK(hipMemsetAsync(s.v.vval, 0, s.nT * sizeof(double), h->stream));
         HIPCHK(hipMemsetAsync(s.v.ifc_cnt, 0, s.nT, h->stream));
         HIPCHK(hipMemsetAsync(s.v.ifc_in, 0, s.nT, h->stream));
         HIPCHK(hipMemsetAsync(s.v.ifc_n, 0, sizeof(int), h->stream));
@@ -433,6 +423,8 @@ int upload_impl(Handle* h, int i_begin, int i_end, const I* state, const double*
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     h->swept = false;
+    if (T) h->table_fresh = false;
+    h->ifc_fresh = false;
     return 0;
 }
 template <class I>
@@ -466,13 +458,33 @@ int launch_interface(Handle* h, bool batch, hipStream_t st, bool long_list = fal
     return 0;
 }
 
+// per-voxel rate table + plane L-1 deposition rates from the current temperature field (stale after an upload of T, a
+// temperature update or a parameter change); it overwrites the listed voxels' entries too, so the interface kernel
+// has to follow
+int ensure_table(Handle* h, hipStream_t st, const StepState* ss)
+{
+    if (h->table_fresh) return 0;
+    const double K0 = host_k_eff(h->p, 0, 0);
+    for (size_t s = 0; s < h->slabs.size(); ++s) {
+        SlabView v = view_of(h, (int)s);
+        const int64_t pairs = (int64_t)v.nloc * v.L * (v.pitchT / 2);
+        hipLaunchKernelGGL(k_rate_table, dim3((unsigned)std::min<int64_t>((pairs + 255) / 256, 8192)), dim3(256), 0, st, h->kp, v, K0, ss);
+        h->cnt.alg_bytes_table += (int64_t)16 * v.nloc * v.L * v.L;     // T read, table entry written
+    }
+    HIPCHK(hipGetLastError());
+    ++h->cnt.table_updates;
+    h->table_fresh = true;
+    h->ifc_fresh = false;
+    return 0;
+}
+
 StreamArgs stream_args(Handle* h, const SlabView& v)
 {
     StreamArgs sa{};
     sa.T_melt = h->kp.T_melt; sa.delta_T_c = h->kp.delta_T_c; sa.kT = h->kp.kT; sa.I0 = h->kp.I0;
-    sa.rate_threshold = h->kp.rate_threshold; sa.nu_dep = h->kp.nu_dep;
+    sa.rate_threshold = h->kp.rate_threshold; sa.K0 = host_k_eff(h->p, 0, 0);
     sa.L = v.L; sa.gi0 = v.gi0; sa.nloc = v.nloc; sa.RJ = v.RJ; sa.pitchC = v.pitchC; sa.pitchT = v.pitchT; sa.Pk = v.Pk;
-    sa.cls = v.cls; sa.T = v.T; sa.ifc_val = v.ifc_val; sa.ifc_cnt = v.ifc_cnt; sa.dep_val = v.dep_val; sa.rowsum = v.rowsum; sa.rowcnt = v.rowcnt;
+    sa.cls = v.cls; sa.T = v.T; sa.vval = v.vval; sa.ifc_cnt = v.ifc_cnt; sa.dep_val = v.dep_val; sa.rowsum = v.rowsum; sa.rowcnt = v.rowcnt;
     sa.group_first = 0; sa.group_count = (v.nloc + STREAM_NI - 1) / STREAM_NI;
     return sa;
 }
@@ -519,8 +531,15 @@ int launch_dirty_rows(Handle* h, hipEvent_t ev_a, hipEvent_t ev_b)
     // the arrival counters live behind the dirty list and are zero at rest)
     for (size_t s = 0; s < h->slabs.size(); ++s) {
         SlabView v = view_of(h, (int)s);
-        hipLaunchKernelGGL(k_rows_eval, dim3(24), dim3(256), 0, h->stream, stream_args(h, v), h->d_ktab, (const int*)h->d_dirty,
-                           (const StepState*)h->d_ss, h->d_blocks, h->d_dirty + 1 + DIRTY_MAX);
+        const StreamArgs sa = stream_args(h, v);
+        const int* dl = h->d_dirty;
+        int* pc = h->d_dirty + 1 + DIRTY_MAX;
+        const StepState* ss = h->d_ss;
+        const bool tab = h->sweep_variant == 1, hw = h->Pk <= 256;
+        if (tab && hw) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows_eval<true, true>), dim3(24), dim3(256), 0, h->stream, sa, dl, ss, h->d_blocks, pc);
+        else if (tab) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows_eval<true, false>), dim3(24), dim3(256), 0, h->stream, sa, dl, ss, h->d_blocks, pc);
+        else if (hw) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows_eval<false, true>), dim3(24), dim3(256), 0, h->stream, sa, dl, ss, h->d_blocks, pc);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows_eval<false, false>), dim3(24), dim3(256), 0, h->stream, sa, dl, ss, h->d_blocks, pc);
     }
     if (ev_b) HIPCHK(hipEventRecord(ev_b, h->stream));
     HIPCHK(hipGetLastError());
@@ -529,33 +548,39 @@ int launch_dirty_rows(Handle* h, hipEvent_t ev_a, hipEvent_t ev_b)
     return 0;
 }
 
-int launch_sweep(Handle* h, bool batch, hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr, bool skip_ifc = false,
-                 bool write_vox = false, hipEvent_t ev_pre = nullptr, hipEvent_t ev_post = nullptr, int wv_box = 0, int wv_sector = 0)
+// One full-lattice rate sweep: (rate table, if T changed) -> (interface kernel, if the listed voxels' sums are stale)
+// -> sweep kernel -> block sums (+ all-gather across ranks).  ev_pre | table + interface | ev_a | sweep | ev_b |
+// reduce | ev_post are the phase boundaries of cetkmc_get_counters.
+int launch_sweep(Handle* h, bool batch, hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr, bool long_list = false,
+                 hipEvent_t ev_pre = nullptr, hipEvent_t ev_post = nullptr)
 {
     ++h->cnt.sweeps;
-    for (auto& sl : h->slabs) h->cnt.alg_bytes_sweep += (int64_t)10 * sl.v.nloc * h->L * h->L;   // cls u16 + T f64 per voxel
+    // streaming kernels: class u8 + one f64 (rate table / T) per voxel; simple kernel: state tile + T
+    for (auto& sl : h->slabs) h->cnt.alg_bytes_sweep += (int64_t)9 * sl.v.nloc * h->L * h->L;
     if (ev_pre) HIPCHK(hipEventRecord(ev_pre, h->stream));
     const int TR = SWEEP_TJ + 4;
     const size_t shmem0 = (size_t)((5 * TR * h->pitchS + 15) & ~15) + 225 * sizeof(double);
     const StepState* ss = batch ? h->d_ss : nullptr;
     const int njt = (h->L + SWEEP_TJ - 1) / SWEEP_TJ;
-    if (h->sweep_variant == 1 && !skip_ifc) CHK(launch_interface(h, batch, h->stream, write_vox));
+    if (h->sweep_variant >= 1) {
+        CHK(ensure_table(h, h->stream, ss));
+        if (!h->ifc_fresh || h->ifc_every_step) {
+            CHK(launch_interface(h, batch, h->stream, long_list));
+            ++h->cnt.interface_launches;
+            h->ifc_fresh = true;
+        }
+    }
     if (ev_a) HIPCHK(hipEventRecord(ev_a, h->stream));
     for (size_t s = 0; s < h->slabs.size(); ++s) {
         SlabView v = view_of(h, (int)s);
-        if (h->sweep_variant == 1) {
-            StreamArgs sa = stream_args(h, v);
-            sa.wv_box = wv_box; sa.wv_sector = wv_sector;
-            const int nib = sa.group_count;
-            const dim3 g8(nib * ((h->L + 7) / 8)), g4(nib * ((h->L + 3) / 4));
-            if (h->stream_tj == 8 && !write_vox)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_stream<8, false>), g8, dim3(256), h->shmem_stream, h->stream, sa, h->d_ktab, ss);
-            else if (h->stream_tj == 8)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_stream<8, true>), g8, dim3(256), h->shmem_stream, h->stream, sa, h->d_ktab, ss);
-            else if (!write_vox)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_stream<4, false>), g4, dim3(256), h->shmem_stream, h->stream, sa, h->d_ktab, ss);
-            else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_stream<4, true>), g4, dim3(256), h->shmem_stream, h->stream, sa, h->d_ktab, ss);
+        if (h->sweep_variant >= 1) {
+            const StreamArgs sa = stream_args(h, v);
+            const dim3 g(sa.group_count * njt);
+            const bool tab = h->sweep_variant == 1, hw = h->Pk <= 256;
+            if (tab && hw) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_stream<true, true>), g, dim3(256), h->shmem_stream, h->stream, sa, ss);
+            else if (tab) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_stream<true, false>), g, dim3(256), h->shmem_stream, h->stream, sa, ss);
+            else if (hw) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_stream<false, true>), g, dim3(256), h->shmem_stream, h->stream, sa, ss);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_stream<false, false>), g, dim3(256), h->shmem_stream, h->stream, sa, ss);
         } else {
             hipLaunchKernelGGL(k_sweep_simple, dim3(v.nloc * njt), dim3(256), shmem0, h->stream, h->kp, v, h->d_ktab, ss);
         }
@@ -577,7 +602,7 @@ int launch_select(Handle* h, const BatchCfg& cfg, double r_direct, int info_only
     hipLaunchKernelGGL(k_select, dim3(1), dim3(256), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
                        (int)h->slabs.size(), h->L, h->PB, (const BlockEnt*)h->d_blocks, h->d_ss, cfg,
                        (const double*)h->d_u_pick, r_direct, (const double*)h->d_ktab,
-                       h->d_events_all + h->my_first, info_only, h->sweep_variant == 1 ? 1 : 0);
+                       h->d_events_all + h->my_first, info_only, h->sweep_variant >= 1 ? 1 : 0);
     HIPCHK(hipGetLastError());
     if (multi_rank(h) && !info_only) CHK(comm_allgather(h, h->d_events_all, sizeof(cetkmc_event)));
     return 0;
@@ -591,7 +616,7 @@ int launch_select_apply(Handle* h, const BatchCfg& cfg, int eval_touched, int* d
         hipLaunchKernelGGL(k_select_apply, dim3(1), dim3(256), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
                            (int)h->slabs.size(), h->L, h->PB, (const BlockEnt*)h->d_blocks, h->d_ss, cfg,
                            (const double*)h->d_u_pick, (const double*)h->d_ktab, h->d_events_all + h->my_first,
-                           h->sweep_variant == 1 ? 1 : 0, (const double*)h->d_u_defect, (const double*)h->d_u_np,
+                           h->sweep_variant >= 1 ? 1 : 0, (const double*)h->d_u_defect, (const double*)h->d_u_np,
                            h->d_log_total, h->d_log_event, h->d_log_nev, eval_touched, dirty);
         HIPCHK(hipGetLastError());
         return 0;
@@ -605,6 +630,39 @@ int launch_select_apply(Handle* h, const BatchCfg& cfg, int eval_touched, int* d
     return 0;
 }
 
+// neighbour exchange along the slab axis: `bytes` from send_lo to rank-1 / send_hi to rank+1 (device pointers), the
+// neighbours' counterparts into recv_lo / recv_hi.  End ranks skip the missing side (its recv buffer is left alone).
+int comm_exchange(Handle* h, const void* send_lo, void* recv_lo, const void* send_hi, void* recv_hi, size_t bytes)
+{
+    if (h->nranks <= 1) return 0;
+    const bool lo = h->rank > 0, hi = h->rank < h->nranks - 1;
+    if (h->comm) {
+        NCCLCHK(g_rccl.GroupStart());
+        if (lo) {
+            NCCLCHK(g_rccl.Send(send_lo, bytes, ncclChar, h->rank - 1, h->comm, h->stream));
+            NCCLCHK(g_rccl.Recv(recv_lo, bytes, ncclChar, h->rank - 1, h->comm, h->stream));
+        }
+        if (hi) {
+            NCCLCHK(g_rccl.Send(send_hi, bytes, ncclChar, h->rank + 1, h->comm, h->stream));
+            NCCLCHK(g_rccl.Recv(recv_hi, bytes, ncclChar, h->rank + 1, h->comm, h->stream));
+        }
+        NCCLCHK(g_rccl.GroupEnd());
+    } else if (h->hc.exchange) {
+        h->hc_stage.resize(std::max(h->hc_stage.size(), 4 * bytes));
+        char* host = h->hc_stage.data();           // [send_lo | send_hi | recv_lo | recv_hi]
+        if (lo) HIPCHK(hipMemcpyAsync(host, send_lo, bytes, hipMemcpyDeviceToHost, h->stream));
+        if (hi) HIPCHK(hipMemcpyAsync(host + bytes, send_hi, bytes, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->hc.exchange(h->hc.user, lo ? h->rank - 1 : -1, hi ? h->rank + 1 : -1, host, host + 2 * bytes, host + bytes, host + 3 * bytes,
+                           (int64_t)bytes))
+            return fail("host neighbour-exchange callback failed");
+        if (lo) HIPCHK(hipMemcpyAsync(recv_lo, host + 2 * bytes, bytes, hipMemcpyHostToDevice, h->stream));
+        if (hi) HIPCHK(hipMemcpyAsync(recv_hi, host + 3 * bytes, bytes, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return 0;
+}
+
 int exchange_T_halo(Handle* h, int buf)
 {
     const size_t plane = (size_t)h->L * h->pitchT;   // doubles
@@ -615,36 +673,11 @@ int exchange_T_halo(Handle* h, int buf)
         HIPCHK(hipMemcpyAsync(b.Tbuf[buf], a.Tbuf[buf] + plane * a.v.nloc, 2 * plane * 8, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(a.Tbuf[buf] + plane * (a.v.nloc + 2), b.Tbuf[buf] + plane * 2, 2 * plane * 8, hipMemcpyDeviceToDevice, h->stream));
     }
-    if (h->comm && h->nranks > 1) {
+    if (multi_rank(h) && h->nranks > 1) {
+        // my bottom / top two owned planes -> the neighbours' halos; theirs -> mine (2 L^2 doubles each way, one xGMI link per side)
         Slab& s = h->slabs[0];
         double* T = s.Tbuf[buf];
-        const size_t cnt = 2 * plane * 8;
-        NCCLCHK(g_rccl.GroupStart());
-        if (h->rank > 0) {
-            NCCLCHK(g_rccl.Send(T + plane * 2, cnt, ncclChar, h->rank - 1, h->comm, h->stream));
-            NCCLCHK(g_rccl.Recv(T, cnt, ncclChar, h->rank - 1, h->comm, h->stream));
-        }
-        if (h->rank < h->nranks - 1) {
-            NCCLCHK(g_rccl.Send(T + plane * s.v.nloc, cnt, ncclChar, h->rank + 1, h->comm, h->stream));
-            NCCLCHK(g_rccl.Recv(T + plane * (s.v.nloc + 2), cnt, ncclChar, h->rank + 1, h->comm, h->stream));
-        }
-        NCCLCHK(g_rccl.GroupEnd());
-    } else if (h->hc.exchange && h->nranks > 1) {
-        Slab& s = h->slabs[0];
-        double* T = s.Tbuf[buf];
-        const size_t cnt = 2 * plane * 8;
-        h->hc_stage.resize(std::max(h->hc_stage.size(), 4 * cnt));
-        char* host = h->hc_stage.data();           // [send_lo | send_hi | recv_lo | recv_hi]
-        const bool lo = h->rank > 0, hi = h->rank < h->nranks - 1;
-        if (lo) HIPCHK(hipMemcpyAsync(host, T + plane * 2, cnt, hipMemcpyDeviceToHost, h->stream));
-        if (hi) HIPCHK(hipMemcpyAsync(host + cnt, T + plane * s.v.nloc, cnt, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        if (h->hc.exchange(h->hc.user, lo ? h->rank - 1 : -1, hi ? h->rank + 1 : -1, host, host + 2 * cnt, host + cnt, host + 3 * cnt,
-                           (int64_t)cnt))
-            return fail("host halo-exchange callback failed");
-        if (lo) HIPCHK(hipMemcpyAsync(T, host + 2 * cnt, cnt, hipMemcpyHostToDevice, h->stream));
-        if (hi) HIPCHK(hipMemcpyAsync(T + plane * (s.v.nloc + 2), host + 3 * cnt, cnt, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        CHK(comm_exchange(h, T + plane * 2, T, T + plane * s.v.nloc, T + plane * (s.v.nloc + 2), 2 * plane * 8));
     }
     return 0;
 }
@@ -684,6 +717,7 @@ int launch_thermal(Handle* h, double dt, int laser, const double* d_q, int use_l
     }
     h->cur = nxt;
     h->swept = false;
+    h->table_fresh = false;
     return 0;
 }
 
@@ -709,7 +743,7 @@ void destroy_impl(Handle* h)
         (void)hipFree(s.v.state); (void)hipFree(s.v.defects); (void)hipFree(s.prev); (void)hipFree(s.v.row_chg); (void)hipFree(s.v.cls);
         (void)hipFree(s.Tbuf[0]); (void)hipFree(s.Tbuf[1]); (void)hipFree(s.v.theta); (void)hipFree(s.v.phi); (void)hipFree(s.v.ovec);
         (void)hipFree(s.v.rowsum); (void)hipFree(s.v.rowcnt);
-        (void)hipFree(s.v.ifc_val); (void)hipFree(s.v.dep_val); (void)hipFree(s.v.ifc_cnt); (void)hipFree(s.v.ifc_in); (void)hipFree(s.v.ifc_code); (void)hipFree(s.v.ifc_list); (void)hipFree(s.v.ifc_n);
+        (void)hipFree(s.v.vval); (void)hipFree(s.v.dep_val); (void)hipFree(s.v.ifc_cnt); (void)hipFree(s.v.ifc_in); (void)hipFree(s.v.ifc_code); (void)hipFree(s.v.ifc_list); (void)hipFree(s.v.ifc_n);
     }
     void* ccp[] = {h->d_cc_parent, h->d_cc_roots, h->d_cc_cid, h->d_cc_labels, h->d_cc_stats, h->d_cc_n};
     for (void* p : ccp) if (p) (void)hipFree(p);
@@ -720,8 +754,6 @@ void destroy_impl(Handle* h)
     for (auto e : h->prof) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
-    if (h->ev_swept) (void)hipEventDestroy(h->ev_swept);
-    if (h->ev_ifc) (void)hipEventDestroy(h->ev_ifc);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -830,7 +862,7 @@ int cetkmc_set_params(void* handle, const cetkmc_params* p)
     if (!h || !p) return fail("null argument");
     HIPCHK(hipSetDevice(h->dev));
     h->p = *p; h->kp = make_kparams(*p);
-    h->swept = false;
+    h->swept = false; h->table_fresh = false; h->ifc_fresh = false;
     return upload_ktab(h);
 }
 
@@ -839,12 +871,12 @@ int cetkmc_set_option(void* handle, const char* key, int64_t value)
     Handle* h = (Handle*)handle;
     if (!h || !key) return fail("null argument");
     if (!strcmp(key, "sweep_variant")) {
-        if (value < 0 || value > 1) return fail("sweep_variant must be 0 (simple) or 1 (streaming, default)");
+        if (value < 0 || value > 2) return fail("sweep_variant must be 0 (simple), 1 (streaming + rate table, default) or 2 (streaming, recompute)");
         h->sweep_variant = (int)value;
-        h->swept = false;
+        h->swept = false; h->table_fresh = false; h->ifc_fresh = false;
         return 0;
     }
-    if (!strcmp(key, "overlap_interface")) { h->overlap_ifc = value ? 1 : 0; return 0; }
+    if (!strcmp(key, "interface_every_step")) { h->ifc_every_step = value ? 1 : 0; h->ifc_fresh = false; return 0; }
     if (!strcmp(key, "thermal_planes_per_block")) {
         if (value < 1 || value > 64) return fail("thermal_planes_per_block must be 1..64");
         h->therm_ni = (int)value;
@@ -915,7 +947,7 @@ int cetkmc_set_defects(void* handle, const uint8_t* mask)
         ext_range(h, s, &a, &b);
         CHK(h2d_u8<uint8_t>(h, s, s.v.defects, mask, 0, a, b, false));
     }
-    h->swept = false;
+    h->swept = false; h->ifc_fresh = false;
     return 0;
 }
 
@@ -936,6 +968,7 @@ int cetkmc_set_prev_state(void* handle, const int64_t* prev_state)
             HIPCHK(hipMemsetAsync(s.v.ifc_in, 0, s.nT, h->stream));
             hipLaunchKernelGGL(k_ifc_rebuild, dim3(2048), dim3(256), 0, h->stream, s.v);
             CHK(relist_slab(h, (int)(&s - h->slabs.data())));
+            h->ifc_fresh = false;
         }
     }
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1010,7 +1043,7 @@ int cetkmc_apply(void* handle, const cetkmc_event* ev, double theta_new, double 
                        (int)h->slabs.size(), e, make_defect, h->d_ss, (const double*)h->d_ktab);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
-    h->swept = false;
+    h->swept = false; h->ifc_fresh = false;      // the touched voxels' codes are current, their sums are not
     return 0;
 }
 
@@ -1128,8 +1161,11 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
                         (a->thermal_mode == 2 ? n_therm * (int64_t)L2 * 8 : 0);
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     int64_t q_idx = 0;
-    bool ifc_fresh = false;     // ifc_val already holds this step's interface sums (speculative launch of the previous step)
-    const bool incr = a->incremental && h->sweep_variant == 1;
+    const bool incr = a->incremental && h->sweep_variant >= 1;
+    // the apply kernel re-evaluates the <= 30 listed voxels an event touches, which keeps every listed voxel's sum
+    // current between temperature updates (the interface kernel then runs only after one); off: the interface kernel
+    // re-evaluates the whole list before every full sweep
+    const int eval_touched = (h->sweep_variant >= 1 && !h->ifc_every_step) ? 1 : 0;
     res->full_sweeps = 0;
     for (int64_t s = 0; s < n; ++s) {
         const int64_t g = a->step0 + s;
@@ -1152,37 +1188,17 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
         }
         ++res->full_sweeps;
         if (a->profile == 2) { was_full[s] = 1; HIPCHK(hipEventRecord(pev(s, 0), h->stream)); }
-        if (a->thermal_mode && g % 20 == 0) {
+        if (therm) {
             if (a->thermal_mode == 1) CHK(launch_thermal(h, a->thermal_dt, 0, nullptr, 0, 1, true));
             else { CHK(launch_thermal(h, a->thermal_dt, 1, h->d_q + (size_t)q_idx * L2, a->use_latent, 1, true)); ++q_idx; }
-            ifc_fresh = false;  // T changed
             if (a->profile == 2) was_thermal[s] = 1;
         }
-        if (a->profile == 2) CHK(launch_sweep(h, true, pev(s, 2), pev(s, 3), ifc_fresh, false, pev(s, 1), pev(s, 4)));
-        else if (sampled(s)) CHK(launch_sweep(h, true, h->prof[2 * s], h->prof[2 * s + 1], ifc_fresh));
-        else CHK(launch_sweep(h, true, nullptr, nullptr, ifc_fresh));
-        // Overlap: the interface sums of step s+1 are evaluated on a second stream while this step reduces
-        // and selects; the apply kernel then re-evaluates the <= 30 listed voxels the event touches, so
-        // every listed voxel is still evaluated in full for every step.  Not worth it before a thermal update.
-        const bool spec = h->overlap_ifc && !incr && h->sweep_variant == 1 && (s + 1 < n) && !(a->thermal_mode && (g + 1) % 20 == 0);
-        if (spec) {
-            HIPCHK(hipEventRecord(h->ev_swept, h->stream));
-            HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_swept, 0));
-            CHK(launch_interface(h, true, h->stream2));
-            HIPCHK(hipEventRecord(h->ev_ifc, h->stream2));
-        }
-        if (spec) {
-            CHK(launch_select(h, cfg, 0.0, 0));
-            HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ifc, 0));
-            hipLaunchKernelGGL(k_apply_batch, dim3(1), dim3(64), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
-                               (int)h->slabs.size(), h->L, (const cetkmc_event*)h->d_events_all, h->G, h->d_ss, cfg,
-                               (const double*)h->d_u_defect, (const double*)h->d_u_np, h->d_log_total, h->d_log_event,
-                               h->d_log_nev, (const double*)h->d_ktab, 1, incr ? h->d_dirty : nullptr);
-        } else {
-            CHK(launch_select_apply(h, cfg, incr ? 1 : 0, incr ? h->d_dirty : nullptr));
-        }
+        if (a->profile == 2) CHK(launch_sweep(h, true, pev(s, 2), pev(s, 3), false, pev(s, 1), pev(s, 4)));
+        else if (sampled(s)) CHK(launch_sweep(h, true, h->prof[2 * s], h->prof[2 * s + 1]));
+        else CHK(launch_sweep(h, true));
+        CHK(launch_select_apply(h, cfg, (incr || eval_touched) ? 1 : 0, incr ? h->d_dirty : nullptr));
+        if (!(incr || eval_touched)) h->ifc_fresh = false;
         if (a->profile == 2) HIPCHK(hipEventRecord(pev(s, 5), h->stream));
-        ifc_fresh = spec;
         h->swept = false;
     }
     HIPCHK(hipGetLastError());
@@ -1258,9 +1274,10 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
     if (!h || !a || !res) return fail("null argument");
     const int64_t n = a->n_steps;
     if (n < 0) return fail("n_steps < 0");
-    if (multi_rank(h) && h->nranks > 1) return fail("cetkmc_run_supersteps: single process only");
-    if (h->sweep_variant != 1) return fail("cetkmc_run_supersteps needs sweep_variant 1");
+    if (h->sweep_variant < 1) return fail("cetkmc_run_supersteps needs a streaming sweep_variant (1 or 2)");
     if (a->box < 8 || a->box > 16 || (a->box & 1) || h->L % a->box) return fail("box must be even, 8..16, and divide L");
+    const bool ranks = multi_rank(h) && h->nranks > 1;
+    if (ranks && (h->L / h->nranks) % a->box) return fail("across ranks the boxes must be aligned to the slabs: (L / nranks) % box == 0");
     int64_t n_therm = 0;
     if (a->thermal_mode) for (int64_t s = 0; s < n; ++s) if ((a->step0 + s) % 20 == 0) ++n_therm;
     if (a->thermal_mode == 2 && (n_therm > a->n_q || (n_therm > 0 && !a->q_planes)))
@@ -1272,7 +1289,13 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
     C.box = a->box; C.H = a->box / 2; C.nb = h->L / a->box;
     C.PH = 1; while (C.PH < C.H) C.PH <<= 1;
     C.PT = 1; while (C.PT < 3 * C.H) C.PT <<= 1;
-    const int D = C.nb * C.nb * C.nb;
+    // this handle's boxes: the box layers of its owned planes (all of them in a single process); global box index
+    // d = (di * nb + dj) * nb + dk, so they are the contiguous range [d0, d0 + D)
+    const int nb2 = C.nb * C.nb;
+    C.d0 = ranks ? (h->own_i0 / a->box) * nb2 : 0;
+    const int D = ranks ? ((h->own_i1 - h->own_i0) / a->box) * nb2 : C.nb * nb2;
+    C.D_loc = D;
+    const int NE = D + 2 * nb2;                               // own events | lower neighbour's top layer | upper neighbour's bottom layer
     const size_t shmem = (size_t)C.PT * C.PH * C.PH * 19;     // heap: 2*NL doubles + 2*NL flags, NL leaf codes
     {
         size_t c1 = h->cap_steps, c2 = h->cap_steps, c3 = h->cap_steps, c4 = h->cap_steps, c5 = h->cap_steps;
@@ -1293,7 +1316,8 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
     DomPick*& d_picks = tmp.picks;
     unsigned long long*& d_cnt = tmp.cnt;
     cetkmc_event*& d_log = tmp.log;
-    HIPCHK(hipMalloc((void**)&d_dom, (size_t)D * sizeof(cetkmc_event)));
+    HIPCHK(hipMalloc((void**)&d_dom, (size_t)NE * sizeof(cetkmc_event)));
+    HIPCHK(hipMemsetAsync(d_dom, 0xFF, (size_t)NE * sizeof(cetkmc_event), h->stream));      // type -1: nothing received
     HIPCHK(hipMalloc((void**)&d_picks, (size_t)D * sizeof(DomPick)));
     HIPCHK(hipMalloc((void**)&d_cnt, 2 * sizeof(unsigned long long)));
     if (events && n > 0) HIPCHK(hipMalloc((void**)&d_log, (size_t)n * D * sizeof(cetkmc_event)));
@@ -1318,19 +1342,27 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
             if (a->thermal_mode == 1) CHK(launch_thermal(h, a->thermal_dt, 0, nullptr, 0, 1, true));
             else { CHK(launch_thermal(h, a->thermal_dt, 1, h->d_q + (size_t)q_idx * L2, a->use_latent, 1, true)); ++q_idx; }
         }
-        // interface sums: the list kernel after a temperature update / at the start of the batch (list rebuilt in
-        // address order first); otherwise they are current -- k_domain_touch re-evaluated what the events changed
-        const bool need_ifc = (s == 0) || therm;
-        if (need_ifc && s > 0) CHK(relist(h));
-        // + per-voxel sums written back for the voxels this super-step's picks read (the active octants)
-        CHK(launch_sweep(h, true, nullptr, nullptr, !need_ifc, true, nullptr, nullptr, C.box, (int)(g & 7)));
+        // interface sums: the list kernel after a temperature update / when something else made them stale (list
+        // rebuilt in address order first: k_domain_touch flags new interface voxels without appending them); otherwise
+        // they are current -- k_domain_touch re-evaluated what the events changed
+        if (s > 0 && (!h->table_fresh || !h->ifc_fresh)) CHK(relist(h));
+        CHK(launch_sweep(h, true, nullptr, nullptr, true));
         CHK(launch_select(h, cfg, 0.0, 1));                              // total, counts, termination test
         hipLaunchKernelGGL(k_domain_pick, dim3(D), dim3(64), shmem, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
                            (int)h->slabs.size(), h->L, C, (const StepState*)h->d_ss, d_picks);
         hipLaunchKernelGGL(k_domain_slot_apply, dim3((D + 63) / 64), dim3(64), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
                            (int)h->slabs.size(), h->L, D, C, h->d_ss, (const DomPick*)d_picks, (const double*)h->d_ktab, d_dom, d_cnt, d_log);
-        hipLaunchKernelGGL(k_domain_touch, dim3((D + 7) / 8), dim3(256), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
-                           (int)h->slabs.size(), D, (const cetkmc_event*)d_dom, (const StepState*)h->d_ss, (const double*)h->d_ktab);
+        int n_touch = D;
+        if (ranks) {
+            // the events of my bottom / top box layer go to the ranks below / above, theirs come here: every rank applies
+            // them to its own copy (owned planes: diffusion targets across the boundary; halo planes: the neighbour's state)
+            CHK(comm_exchange(h, d_dom, d_dom + D, d_dom + (D - nb2), d_dom + D + nb2, (size_t)nb2 * sizeof(cetkmc_event)));
+            hipLaunchKernelGGL(k_domain_apply_remote, dim3((2 * nb2 + 63) / 64), dim3(64), 0, h->stream, (const SlabView*)h->d_views[h->cur],
+                               (int)h->slabs.size(), C, (const StepState*)h->d_ss, (const cetkmc_event*)(d_dom + D));
+            n_touch = NE;
+        }
+        hipLaunchKernelGGL(k_domain_touch, dim3((n_touch + 7) / 8), dim3(256), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
+                           (int)h->slabs.size(), n_touch, (const cetkmc_event*)d_dom, (const StepState*)h->d_ss, (const double*)h->d_ktab);
         hipLaunchKernelGGL(k_super_commit, dim3(1), dim3(1), 0, h->stream, h->d_ss, d_cnt, h->d_log_total, h->d_log_nev);
         h->swept = false;
     }
@@ -1491,7 +1523,7 @@ int cetkmc_set_defects_sparse(void* handle, const int64_t* lin_idx, int64_t n)
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
-    h->swept = false;
+    h->swept = false; h->ifc_fresh = false;
     return 0;
 }
 

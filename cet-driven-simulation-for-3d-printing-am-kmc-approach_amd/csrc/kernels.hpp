@@ -41,13 +41,11 @@ struct BatchCfg {
     int32_t batch;      // 1: r = u_pick[cur]*total and RNG bookkeeping; 0: direct r
 };
 
-#ifndef CETKMC_SWEEP_UNROLL
-#define CETKMC_SWEEP_UNROLL 2      // voxels of a lane's 4 evaluated per trip of the per-voxel loop (4: 137 VGPRs, 3 waves/SIMD)
-#endif
 #ifndef CETKMC_SWEEP_ATTR
 #define CETKMC_SWEEP_ATTR          // e.g. __attribute__((amdgpu_waves_per_eu(4, 4))) for A/B builds
 #endif
 constexpr int SWEEP_TJ = 8;        // rows of one plane per sweep block
+constexpr int L_INACTIVE = 1 << 20; // row index of an idle half-wave (>= any L)
 constexpr int PMAX = 2048;         // max leaves of an LDS heap tree (3L <= PMAX)
 
 // Balanced binary tree over the 64 lanes, result in every lane.  Levels 1,2 use quad_perm DPP,
@@ -196,18 +194,23 @@ __global__ __launch_bounds__(256) void k_sweep_simple(KParams P, SlabView S, con
 }
 
 // ----------------------------------------------------------------------------------------
-// k_sweep_stream (variant 1, default): 2.5-D blocking.  One block owns SWEEP_TJ rows and
-// marches over STREAM_NI consecutive planes, keeping a 5-plane ring of the u16 census-class
-// array in LDS (each class word is fetched ~1.9x instead of 7.5x).  A lane handles 4
-// consecutive voxels of a row: the 14-neighbour census (#in-bounds, #empty, #W/Re/C, #Re/C)
-// of all 4 voxels is 17 LDS loads + SWAR adds on packed 4-bit counters -- no compares.
-// T is streamed once (32 B per lane).  Interface voxels (census says: empty with a W/Re/C
-// neighbour, or atom with an empty neighbour) take their category sum from ifc_val/ifc_cnt,
-// which k_interface filled in this step; all other empty voxels get their nucleation rate
-// here.  Row sums follow the canonical tree: 4-voxel tree, wave butterfly, chunk tree.
+// k_sweep_stream (variants 1 and 2): 2.5-D blocking.  One block owns SWEEP_TJ rows and marches over
+// STREAM_NI consecutive planes, keeping a 6-slot ring of the u8 census-class array in LDS (5 planes of the
+// stencil + the next plane's slab in flight).  A lane handles 8 consecutive voxels of a row: the 14-neighbour
+// census of all 8 is 17 LDS loads + OR / v_alignbyte on packed bytes -- no compares, no counters.
+//   TAB (variant 1, default): the per-voxel rate table vval is streamed (64 B per lane): an empty voxel's
+//     EMPTY-category sum / an atom's DIFF-category sum is the table entry, the census decides which voxels
+//     count (empty; atom with an empty neighbour) and which are interface voxels (event count from ifc_cnt).
+//   !TAB (variant 2, "recompute"): T is streamed instead and the nucleation rate of every empty voxel without
+//     W/Re/C neighbours is evaluated in the sweep (Newton reciprocal + 14-FMA exp per voxel); interface voxels
+//     take their sums from vval.  Same bits as variant 1 (k_rate_table evaluates the same nuc_bulk()).
+// Plane L-1 adds the deposition rates (dep_val, by temperature).  Row sums follow the canonical tree: 8-voxel
+// tree in the lane, DPP / v_permlane*_swap butterfly, chunk tree; event counts are scalar popcounts of ballots.
+// HW: rows of <= 256 voxels occupy half a wave, a wave then carries two rows.
 // ----------------------------------------------------------------------------------------
 constexpr int STREAM_NI = 8;      // planes per block
-constexpr int STREAM_MAXCH = 4;   // chunks of 256 voxels per row (L <= 1024)
+constexpr int STREAM_SLOTS = 6;   // ring slots
+constexpr int STREAM_MAXPF = 3;   // 16-B chunks of a class slab per thread (L <= 682: 12 rows x 704 B = 528 chunks)
 
 // Block sum of (owned plane lp, category c) by one wave: balanced tree over j of the row sums.  COH: some row sums
 // were written by other blocks of the SAME launch (k_rows_eval's in-launch reduction) -> agent-scope loads.
@@ -240,155 +243,242 @@ __device__ __forceinline__ void plane_reduce_wave(const double* rowsum, const in
 }
 
 struct StreamArgs {
-    double T_melt, delta_T_c, kT, I0, rate_threshold, nu_dep;
+    double T_melt, delta_T_c, kT, I0, rate_threshold, K0;    // K0 = K_eff without W/Re/C neighbours (ktab[0])
     int L, gi0, nloc, RJ, pitchC, pitchT, Pk, group_first, group_count;
-    int wv_box, wv_sector;    // write-back instantiation: only voxels of the boxes' active octant are stored (wv_box 0: all)
-    const uint16_t* cls;
-    const double* T;
-    double* ifc_val;          // read; written for non-interface voxels by the write-back instantiation (Mode B)
-    uint8_t* ifc_cnt;
+    const uint8_t* cls;
+    const double* T;          // streamed by the recompute variant
+    const double* vval;       // streamed by the table variant; gathered at interface voxels by the recompute variant
+    const uint8_t* ifc_cnt;
     const double* dep_val;    // plane L-1 deposition rates by temperature (SlabView::dep_val)
     double* rowsum;
     int32_t* rowcnt;
 };
 
-__device__ __forceinline__ unsigned alignbit16(unsigned hi, unsigned lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
+// kmc_event_rates.py:116-131 for an empty voxel WITHOUT W/Re/C neighbours: n_imp = 0, hence f_imp = 0 and
+// K_eff = clamp(K_nuc) = K0 whatever the neighbour count; the rate is a function of the temperature alone.  0 when
+// the voxel owns no nucleation event (dT <= delta_T_c, rate <= threshold or not finite).  Same arithmetic as
+// eval_voxel()/ifc_eval_empty() with n_imp = 0, so every kernel agrees to the bit.
+__device__ __forceinline__ double nuc_bulk(double T_melt, double delta_T_c, double kT, double I0, double thr, double K0, double Traw)
+{
+    const double Tc = pymax(Traw, 1.0);
+    const double dT = T_melt - Tc;
+    double r = 0.0;
+    if (dT > delta_T_c) {
+        r = nuc_rate_s(I0, K0, dT, kT * Tc);
+        if (!(r > thr && finite_d(r))) r = 0.0;
+    }
+    return r;
+}
 
-// One lattice row (plane li, row j) by one wave: census + rates + canonical row reduction, results to
-// rowsum/rowcnt.  `rowp(d, dj)` returns the class-row pointer (at k = 0) of plane li+d, row j+dj -- an LDS
-// ring slot in the streaming kernel, the global class array in the dirty-row kernel; everything else is
-// shared, so both produce bit-identical row sums.  `rp` = LDS scratch [3][STREAM_MAXCH] of this row.
-// WV (Mode B only): also store every non-interface voxel's EMPTY/DIFF category sum and count into ifc_val/ifc_cnt,
-// so that afterwards those arrays are valid for ALL owned voxels (interface voxels were written by k_interface).
-template <bool WV, class ROWP>
-__device__ __forceinline__ void sweep_row(const StreamArgs& A, const double* ktab, double* rp, ROWP rowp,
-                                          int li, int lp, int j, bool top, int lane, int nch)
+// half == true: butterfly over the 32 lanes of each half-wave only
+template <bool HALF>
+__device__ __forceinline__ double wave_tree_sum_h(double v)
+{
+    v = v + dpp_f64(v, 0);
+    v = v + dpp_f64(v, 1);
+    v = v + dpp_f64(v, 2);
+    v = v + dpp_f64(v, 3);
+    {
+        const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+        const auto r0 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto r1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __hiloint2double((int)r1[0], (int)r0[0]) + __hiloint2double((int)r1[1], (int)r0[1]);
+    }
+    if (!HALF) {
+        const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+        const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = __hiloint2double((int)r1[0], (int)r0[0]) + __hiloint2double((int)r1[1], (int)r0[1]);
+    }
+    return v;
+}
+template <bool HALF>
+__device__ __forceinline__ int wave_sum_i_h(int v)
+{
+    v += (int)__builtin_amdgcn_update_dpp(0u, (unsigned)v, 0xB1, 0xF, 0xF, false);
+    v += (int)__builtin_amdgcn_update_dpp(0u, (unsigned)v, 0x4E, 0xF, 0xF, false);
+    v += (int)__builtin_amdgcn_update_dpp(0u, (unsigned)v, 0x141, 0xF, 0xF, false);
+    v += (int)__builtin_amdgcn_update_dpp(0u, (unsigned)v, 0x140, 0xF, 0xF, false);
+    { const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false); v = (int)(r[0] + r[1]); }
+    if (!HALF) { const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false); v = (int)(r[0] + r[1]); }
+    return v;
+}
+
+__device__ __forceinline__ unsigned alignbyte(unsigned hi, unsigned lo, unsigned n) { return __builtin_amdgcn_alignbyte(hi, lo, n); }
+// v & (bit b of w ? ~0 : 0): one v_bfe_i32 + two v_and_b32
+__device__ __forceinline__ double mask_f64(double v, unsigned w, int b)
+{
+    const int m = __builtin_amdgcn_sbfe(w, b, 1);
+    return __hiloint2double(__double2hiint(v) & m, __double2loint(v) & m);
+}
+__device__ __forceinline__ double tree8(const double (&x)[8])
+{
+    return ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+}
+
+// One lattice row per wave (HW: per half-wave; `jrow` is then the lane's own row) of plane li: census + rates +
+// canonical row reduction, results to rowsum/rowcnt.  `rowp(d, dj)` returns the class-row pointer (at k = 0) of plane
+// li+d, row jrow+dj -- an LDS ring slot in the streaming kernel, the global class array in the dirty-row kernel;
+// everything else is shared, so both produce bit-identical row sums.
+template <bool TAB, bool HW, class ROWP>
+__device__ __forceinline__ void sweep_row(const StreamArgs& A, ROWP rowp, int li, int lp, int jrow, bool top, int lane)
 {
     const int L = A.L;
-    int cdep = 0, cdiff = 0, cemp = 0;
-    // Mode B write-back: is (plane, row) / is column k inside the active octant of its box?
-    const int wv_h = A.wv_box >> 1;
-    const bool wv_row = !WV || !A.wv_box ||
-        ((((A.gi0 + lp) % A.wv_box) >= wv_h) == (((A.wv_sector >> 2) & 1) != 0) && ((j % A.wv_box) >= wv_h) == (((A.wv_sector >> 1) & 1) != 0));
-    auto wv_k = [&](int k) { return ((k % A.wv_box) >= wv_h) == ((A.wv_sector & 1) != 0); };
+    const int sl = HW ? (lane & 31) : lane;
+    const int nch = HW ? 1 : (A.Pk >> 9);                    // chunks of 512 voxels (Pk >= 512 unless HW)
+    double r0 = 0.0, r1 = 0.0, r2 = 0.0;                     // row totals (chunk tree: nch <= 2)
+    int nE_a = 0, nE_b = 0, nD_a = 0, nD_b = 0;              // scalar event counts: whole wave / half a, half b
+    int cI = 0;                                              // lane: interface counts, EMPTY | DIFF << 16
+    bool any_ifc = false;
 #pragma unroll 1
     for (int m = 0; m < nch; ++m) {
-        const int k0 = (m << 8) + 4 * lane;
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0;     // 4-voxel trees (v0+v1)+(v2+v3), built pair by pair
-        if (j < L && k0 < L) {
-            const int64_t trow = ((int64_t)li * L + j) * A.pitchT + k0;
-            const double2 Ta = *reinterpret_cast<const double2*>(A.T + trow);
-            const double2 Tb = (k0 + 2 < L) ? *reinterpret_cast<const double2*>(A.T + trow + 2) : make_double2(0.0, 0.0);
-            // ---- SWAR census of the 4 voxels' 14 neighbours ------------------------------
-            auto ld2 = [&](const uint16_t* p) { return *reinterpret_cast<const uint2*>(p + k0); };
-            auto ld1 = [&](const uint16_t* p) { return *reinterpret_cast<const unsigned*>(p + k0); };
-            uint2 acc = ld2(rowp(1, 1));
-            uint2 t;
-            t = ld2(rowp(1, -1)); acc.x += t.x; acc.y += t.y;
-            t = ld2(rowp(-1, 1)); acc.x += t.x; acc.y += t.y;
-            t = ld2(rowp(-1, -1)); acc.x += t.x; acc.y += t.y;
-            t = ld2(rowp(2, 0)); acc.x += t.x; acc.y += t.y;
-            t = ld2(rowp(-2, 0)); acc.x += t.x; acc.y += t.y;
-            t = ld2(rowp(0, 2)); acc.x += t.x; acc.y += t.y;
-            t = ld2(rowp(0, -2)); acc.x += t.x; acc.y += t.y;
+        const int k0 = (m << 9) + 8 * sl;
+        const bool active = jrow < L && k0 < L;
+        const int64_t trow = ((int64_t)li * L + jrow) * A.pitchT + k0;
+        double v[8], ev[8];
+        uint2 own = make_uint2(0u, 0u), acc = make_uint2(0u, 0u);
 #pragma unroll
-            for (int dj = -1; dj <= 1; dj += 2) {          // (0,dj,+-1): neighbours k-1 and k+1
-                const uint16_t* p = rowp(0, dj);
-                const unsigned Aw = ld1(p - 2), Cw = ld1(p + 4);
-                const uint2 B = ld2(p);
-                const unsigned m1 = alignbit16(B.x, Aw), m2 = alignbit16(B.y, B.x), m3 = alignbit16(Cw, B.y);
-                acc.x += m1 + m2; acc.y += m2 + m3;
+        for (int q = 0; q < 8; ++q) v[q] = 0.0;
+        if (active) {
+            const double* src = (TAB ? A.vval : A.T) + trow;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (k0 + 2 * q < L) { const double2 t = *reinterpret_cast<const double2*>(src + 2 * q); v[2 * q] = t.x; v[2 * q + 1] = t.y; }
+            // ---- census of the 8 voxels' 14 neighbours: OR of class bytes ---------------------------
+            auto ld8 = [&](const uint8_t* p) { return *reinterpret_cast<const uint2*>(p + k0); };
+            auto ld4 = [&](const uint8_t* p, int off) { return *reinterpret_cast<const unsigned*>(p + k0 + off); };
+            uint2 t;
+            acc = ld8(rowp(1, 1));
+            t = ld8(rowp(1, -1)); acc.x |= t.x; acc.y |= t.y;
+            t = ld8(rowp(-1, 1)); acc.x |= t.x; acc.y |= t.y;
+            t = ld8(rowp(-1, -1)); acc.x |= t.x; acc.y |= t.y;
+            t = ld8(rowp(2, 0)); acc.x |= t.x; acc.y |= t.y;
+            t = ld8(rowp(-2, 0)); acc.x |= t.x; acc.y |= t.y;
+            t = ld8(rowp(0, 2)); acc.x |= t.x; acc.y |= t.y;
+            t = ld8(rowp(0, -2)); acc.x |= t.x; acc.y |= t.y;
+#pragma unroll
+            for (int dj = -1; dj <= 1; dj += 2) {                  // (0,dj,+-1): neighbours k-1 and k+1
+                const uint8_t* p = rowp(0, dj);
+                const unsigned Aw = ld4(p, -4), Cw = ld4(p, 8);
+                const uint2 B = ld8(p);
+                const unsigned mid = alignbyte(B.y, B.x, 1);       // bytes k0+1 .. k0+4
+                acc.x |= alignbyte(B.x, Aw, 3) | mid;
+                acc.y |= alignbyte(B.y, B.x, 3) | alignbyte(Cw, B.y, 1);
             }
-            const uint16_t* po = rowp(0, 0);                 // own row: neighbours k-2 and k+2
-            const unsigned Aw = ld1(po - 2), Cw = ld1(po + 4);
-            const uint2 own = ld2(po);
-            acc.x += Aw + own.y; acc.y += own.x + Cw;
-            // ---- per-voxel part (two voxels per trip: keeps the register footprint small) ----
-            double p0 = 0.0, p1 = 0.0, p2 = 0.0;             // even voxel of the current pair
-            double pw = 0.0;                                 // WV: value / count of the even voxel
-            unsigned pc = 0;
-#pragma unroll CETKMC_SWEEP_UNROLL
-            for (int h = 0; h < 4; ++h) {
-                const int sh = 16 * (h & 1);
-                const unsigned f = ((h < 2 ? acc.x : acc.y) >> sh) & 0xFFFFu;
-                const unsigned oc = ((h < 2 ? own.x : own.y) >> sh) & 0xFFFFu;
-                const bool empty = (oc & 0x10u) != 0;
-                double ev = 0.0, dv = 0.0, depv = 0.0;
-                unsigned wc = 0;
-                if (empty) {
-                    const double Traw = (h < 2) ? (h == 0 ? Ta.x : Ta.y) : (h == 2 ? Tb.x : Tb.y);
-                    const double Tc = pymax(Traw, 1.0);
-                    if (top) {          // nu_dep * exp(-(T_melt - T')/(kT T')), evaluated per sweep by k_interface's tail
-                        const double rate = A.dep_val[(int64_t)j * A.pitchT + k0 + h];
-                        if (finite_d(rate)) { depv = rate; ++cdep; }
-                    }
-                    if (f & 0x0F00u) {                       // has W/Re/C neighbours: interface voxel
-                        ev = A.ifc_val[trow + h];
-                        wc = A.ifc_cnt[trow + h];
-                        cemp += wc;
-                    } else {
-                        const double dT = A.T_melt - Tc;
-                        if (dT > A.delta_T_c) {
-                            const int n_nb = f & 15, n_imp = (f >> 12) & 15;
-                            const double rate = nuc_rate_s(A.I0, ktab[n_nb * 15 + n_imp], dT, A.kT * Tc);
-                            if (rate > A.rate_threshold) { ev = rate; ++cemp; wc = 1; }   // <= I0: always finite
-                        }
-                    }
-                } else if ((oc & 0x100u) && (f & 0x00F0u)) { // atom with empty neighbours
-                    dv = A.ifc_val[trow + h];
-                    wc = A.ifc_cnt[trow + h];
-                    cdiff += wc;
-                }
-                if (WV && wv_row) {     // uniform per row: rows outside the active octants run the plain loop
-                    // every voxel's EMPTY-or-DIFF sum goes back (interface voxels: the value just loaded), one
-                    // 16-byte + one 2-byte store per voxel pair
-                    const double wv = empty ? ev : dv;
-                    if (!(h & 1)) { pw = wv; pc = wc; }
-                    else if (k0 + h - 1 < L && (!A.wv_box || wv_k(k0 + h - 1) || wv_k(k0 + h))) {
-                        *reinterpret_cast<double2*>(A.ifc_val + trow + h - 1) = make_double2(pw, wv);
-                        *reinterpret_cast<uint16_t*>(A.ifc_cnt + trow + h - 1) = (uint16_t)(pc | (wc << 8));
-                    }
-                }
-                if (!(h & 1)) { p0 = depv; p1 = dv; p2 = ev; }
-                else if (h == 1) { s0 = p0 + depv; s1 = p1 + dv; s2 = p2 + ev; }
-                else { s0 = s0 + (p0 + depv); s1 = s1 + (p1 + dv); s2 = s2 + (p2 + ev); }
+            const uint8_t* po = rowp(0, 0);                        // own row: neighbours k-2 and k+2
+            const unsigned Aw = ld4(po, -4), Cw = ld4(po, 8);
+            own = ld8(po);
+            const unsigned mid = alignbyte(own.y, own.x, 2);       // bytes k0+2 .. k0+5
+            acc.x |= alignbyte(own.x, Aw, 2) | mid;
+            acc.y |= mid | alignbyte(Cw, own.y, 2);
+        }
+        // bit 0 of every byte: E own voxel empty; ifE empty with a W/Re/C neighbour (attachment: interface voxel);
+        // ifA W/Re/C atom with an empty neighbour (diffusion: interface voxel)
+        const uint2 E = make_uint2(own.x & 0x01010101u, own.y & 0x01010101u);
+        const uint2 ifE = make_uint2(E.x & (acc.x >> 1), E.y & (acc.y >> 1));
+        const uint2 ifA = make_uint2((own.x >> 1) & acc.x & 0x01010101u, (own.y >> 1) & acc.y & 0x01010101u);
+        // ---- EMPTY category ---------------------------------------------------------------------------
+        if (TAB) {
+#pragma unroll
+            for (int h = 0; h < 8; ++h) ev[h] = mask_f64(v[h], h < 4 ? E.x : E.y, 8 * (h & 3));
+        } else {
+            const uint2 bulk = make_uint2(E.x & ~ifE.x, E.y & ~ifE.y);
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                ev[h] = 0.0;
+                if (((h < 4 ? bulk.x : bulk.y) >> (8 * (h & 3))) & 1u)
+                    ev[h] = nuc_bulk(A.T_melt, A.delta_T_c, A.kT, A.I0, A.rate_threshold, A.K0, v[h]);
             }
         }
-        // ---- wave butterfly, chunk partial to LDS ---------------------------------------------
-        if (__any(s2 != 0.0)) s2 = wave_tree_sum(s2);
-        if (__any(s1 != 0.0)) s1 = wave_tree_sum(s1);
-        if (top && __any(s0 != 0.0)) s0 = wave_tree_sum(s0);
-        if (lane == 0) {
-            rp[0 * STREAM_MAXCH + m] = s0;
-            rp[1 * STREAM_MAXCH + m] = s1;
-            rp[2 * STREAM_MAXCH + m] = s2;
+        // ---- interface voxels of the lane: event counts (and, recompute variant, their sums) ------------
+        const unsigned long long ibits = ((unsigned long long)(ifE.y | ifA.y) << 32) | (ifE.x | ifA.x);
+        const unsigned long long ebits = ((unsigned long long)ifE.y << 32) | ifE.x;
+        double dv[8];
+#pragma unroll
+        for (int h = 0; h < 8; ++h) dv[h] = 0.0;
+        const bool diff_here = __any((ifA.x | ifA.y) != 0u);
+        if (__any(ibits != 0ull)) {
+            any_ifc = true;
+            unsigned long long bits = ibits;
+            while (bits) {
+                const int b = __builtin_ctzll(bits);
+                bits &= bits - 1;
+                const int h = b >> 3;
+                const int c = A.ifc_cnt[trow + h];
+                const bool isE = (ebits >> b) & 1ull;
+                // the ballots below count an empty voxel with a non-zero EMPTY-category sum once: an interface voxel's
+                // sum is non-zero iff it owns events (every kept rate is > rate_threshold)
+                cI += isE ? (c - (c > 0)) : (c << 16);
+                if (!TAB) {
+                    const double x = A.vval[trow + h];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        if (q == h && isE) ev[q] = x;
+                        if (q == h && !isE) dv[q] = x;
+                    }
+                }
+            }
+        }
+        if (TAB && diff_here) {
+#pragma unroll
+            for (int h = 0; h < 8; ++h) dv[h] = mask_f64(v[h], h < 4 ? ifA.x : ifA.y, 8 * (h & 3));
+        }
+        // ---- counts: scalar popcounts of ballots (bulk voxels count iff their rate is kept) -------------
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            const unsigned long long bm = __ballot(ev[h] != 0.0);
+            if (HW) { nE_a += __popc((unsigned)bm); nE_b += __popc((unsigned)(bm >> 32)); }
+            else nE_a += __popcll(bm);
+        }
+        // ---- sums: 8-voxel tree, wave butterfly, chunk tree ------------------------------------------------
+        double s2 = wave_tree_sum_h<HW>(tree8(ev));
+        r2 = (m == 0) ? s2 : r2 + s2;
+        double s1 = 0.0;                                         // a chunk without diffusing atoms contributes +0.0
+        if (diff_here) s1 = wave_tree_sum_h<HW>(tree8(dv));
+        r1 = (m == 0) ? s1 : r1 + s1;
+        if (top) {          // nu_dep * exp(-(T_melt - T')/(kT T')) of plane L-1 by temperature (k_rate_table): kept iff finite
+            double dp[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dp[q] = 0.0;
+            if (active) {
+                const double* src = A.dep_val + (int64_t)jrow * A.pitchT + k0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (k0 + 2 * q < L) { const double2 t = *reinterpret_cast<const double2*>(src + 2 * q); dp[2 * q] = t.x; dp[2 * q + 1] = t.y; }
+            }
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                const bool keep = (((h < 4 ? E.x : E.y) >> (8 * (h & 3))) & 1u) && finite_d(dp[h]);
+                dp[h] = keep ? dp[h] : 0.0;
+                const unsigned long long bm = __ballot(keep);
+                if (HW) { nD_a += __popc((unsigned)bm); nD_b += __popc((unsigned)(bm >> 32)); }
+                else nD_a += __popcll(bm);
+            }
+            const double s0 = wave_tree_sum_h<HW>(tree8(dp));
+            r0 = (m == 0) ? s0 : r0 + s0;
         }
     }
-    // ---- row totals: balanced tree over the chunk partials; counts reduced once ------------
-    // per-lane counts are <= 4*nch*15 < 2^10 each, so diff and empty share one integer butterfly
-    const int packed = wave_sum_i(cemp | (cdiff << 16));
-    const int n2 = packed & 0xFFFF, n1 = packed >> 16;
-    const int n0 = top ? wave_sum_i(cdep) : 0;
-    if (lane == 0 && j < L) {
-        const int64_t o = (int64_t)lp * 3 * L + j;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            double* p = rp + c * STREAM_MAXCH;
-            for (int n = nch; n > 1; n >>= 1)
-                for (int t = 0; t < (n >> 1); ++t) p[t] = p[2 * t] + p[2 * t + 1];
-            A.rowsum[o + (int64_t)c * L] = p[0];
-        }
-        A.rowcnt[o] = n0; A.rowcnt[o + L] = n1; A.rowcnt[o + 2 * L] = n2;
+    int n2 = HW ? ((lane & 32) ? nE_b : nE_a) : nE_a;
+    const int n0 = HW ? ((lane & 32) ? nD_b : nD_a) : nD_a;
+    int n1 = 0;
+    if (any_ifc) {
+        const int packed = wave_sum_i_h<HW>(cI);
+        n2 += packed & 0xFFFF;
+        n1 = packed >> 16;
+    }
+    if (sl == 0 && jrow < L) {
+        const int64_t o = (int64_t)lp * 3 * L + jrow;
+        A.rowsum[o] = r0; A.rowsum[o + L] = r1; A.rowsum[o + 2 * (int64_t)L] = r2;
+        A.rowcnt[o] = n0; A.rowcnt[o + L] = n1; A.rowcnt[o + 2 * (int64_t)L] = n2;
     }
 }
 
-template <int TJ, bool WV>
-__global__ __launch_bounds__(256) CETKMC_SWEEP_ATTR void k_sweep_stream(StreamArgs A, const double* __restrict__ ktab_g,
-                                                      const StepState* __restrict__ ss)
+template <bool TAB, bool HW>
+__global__ __launch_bounds__(256) CETKMC_SWEEP_ATTR void k_sweep_stream(StreamArgs A, const StepState* __restrict__ ss)
 {
     if (ss && ss->status) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int TR = TJ + 4;          // TJ = rows per block: 8 (two per wave) or 4 (one per wave, smaller ring for large L)
+    constexpr int TJ = SWEEP_TJ, TR = TJ + 4;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int L = A.L;
     const int njt = (L + TJ - 1) / TJ;
@@ -399,53 +489,59 @@ __global__ __launch_bounds__(256) CETKMC_SWEEP_ATTR void k_sweep_stream(StreamAr
     const int j0 = jt * TJ;
     const int lp0 = (A.group_first + ibr) * STREAM_NI, lp1 = min(lp0 + STREAM_NI, A.nloc);
     const int pitchC = A.pitchC;
-    const int slab = TR * pitchC;                                     // u16 per plane slab
-    uint16_t* ring = reinterpret_cast<uint16_t*>(smem);
-    const int ring_bytes = (5 * slab * 2 + 15) & ~15;
-    double* ktab = reinterpret_cast<double*>(smem + ring_bytes);      // [226]
-    double* rowpart = ktab + 226;                                     // [TJ][3][STREAM_MAXCH]
-
-    const int cpr = pitchC >> 3;                                      // 16-B chunks per class row
-    auto load_slab = [&](int lsrc) {
+    const int slab = TR * pitchC;                                     // bytes per plane slab
+    const int nchunk = slab >> 4;                                     // 16-B chunks per slab
+    // class slab of local plane lsrc (rows j0-2 .. j0+TJ+1) -> registers -> ring slot lsrc % STREAM_SLOTS
+    uint4 pf[STREAM_MAXPF];
+    auto fetch_slab = [&](int lsrc) {
         const uint4* src = reinterpret_cast<const uint4*>(A.cls + ((int64_t)lsrc * A.RJ + j0) * pitchC);
-        uint4* dst = reinterpret_cast<uint4*>(ring + (lsrc % 5) * slab);
-        for (int idx = tid; idx < TR * cpr; idx += 256) dst[idx] = src[idx];
+#pragma unroll
+        for (int q = 0; q < STREAM_MAXPF; ++q) { const int idx = tid + 256 * q; if (idx < nchunk) pf[q] = src[idx]; }
     };
-    for (int d = 0; d < 4; ++d) load_slab(lp0 + d);                   // planes li-2 .. li+1 of the first plane
-    if (tid < 225) ktab[tid] = ktab_g[tid];
-
-    const int nch = A.Pk > 256 ? (A.Pk >> 8) : 1;
+    auto store_slab = [&](int lsrc) {
+        uint4* dst = reinterpret_cast<uint4*>(smem + (lsrc % STREAM_SLOTS) * slab);
+#pragma unroll
+        for (int q = 0; q < STREAM_MAXPF; ++q) { const int idx = tid + 256 * q; if (idx < nchunk) dst[idx] = pf[q]; }
+    };
+    for (int d = 0; d < 5; ++d) { fetch_slab(lp0 + d); store_slab(lp0 + d); }     // planes li-2 .. li+2 of the first plane
+    __syncthreads();
 #pragma unroll 1
     for (int lp = lp0; lp < lp1; ++lp) {
         const int li = lp + 2;
         const bool top = (A.gi0 + lp == L - 1);
-        load_slab(li + 2);
-        __syncthreads();
+        const bool more = lp + 1 < lp1;
+        if (more) fetch_slab(li + 3);                                // next plane's new slab: in flight during this plane
         int so[5];
 #pragma unroll
-        for (int d = 0; d < 5; ++d) so[d] = ((li - 2 + d) % 5) * slab;
+        for (int d = 0; d < 5; ++d) so[d] = ((li - 2 + d) % STREAM_SLOTS) * slab;
+        if (HW) {
+            const int r = 2 * w + (lane >> 5);
+            auto rowp = [&](int d, int dj) { return (const uint8_t*)smem + so[d + 2] + (r + 2 + dj) * pitchC + KOFFC; };
+            sweep_row<TAB, true>(A, rowp, li, lp, j0 + r, top, lane);
+        } else {
 #pragma unroll 1
-        for (int rr = 0; rr < TJ / 4; ++rr) {
-            const int r = w + 4 * rr;
-            auto rowp = [&](int d, int dj) { return ring + so[d + 2] + (r + 2 + dj) * pitchC + KOFFC; };
-            sweep_row<WV>(A, ktab, rowpart + r * 3 * STREAM_MAXCH, rowp, li, lp, j0 + r, top, lane, nch);
+            for (int rr = 0; rr < TJ / 4; ++rr) {
+                const int r = w + 4 * rr;
+                auto rowp = [&](int d, int dj) { return (const uint8_t*)smem + so[d + 2] + (r + 2 + dj) * pitchC + KOFFC; };
+                sweep_row<TAB, false>(A, rowp, li, lp, j0 + r, top, lane);
+            }
         }
-        __syncthreads();   // ring slot (li-2)%5 is overwritten by the next plane's load
+        if (more) store_slab(li + 3);        // the sixth slot: not among the five this plane's stencil reads
+        __syncthreads();
     }
 }
 
 // Exact incremental stepping: between two temperature updates an event changes the rates of a few rows
 // only (those holding the changed voxel(s) or one of their 14 neighbours).  k_apply_batch records those
-// rows; this kernel re-evaluates just them -- one wave per row, class words read straight from global
+// rows; this kernel re-evaluates just them -- one wave per row, class bytes read straight from global
 // memory -- with the same sweep_row() as the streaming kernel, so every row sum equals what a full sweep
 // would have produced.  dirty[0] = count, dirty[1..] = (global plane << 16) | row.
 constexpr int DIRTY_MAX = 63;
-__global__ __launch_bounds__(256) void k_rows_eval(StreamArgs A, const double* __restrict__ ktab_g, const int* __restrict__ dirty,
+template <bool TAB, bool HW>
+__global__ __launch_bounds__(256) void k_rows_eval(StreamArgs A, const int* __restrict__ dirty,
                                                    const StepState* __restrict__ ss, BlockEnt* __restrict__ blocks, int* plane_cnt)
 {
     if (ss && ss->status) return;
-    __shared__ double ktab[226];
-    __shared__ double rp[3 * STREAM_MAXCH];
     __shared__ int sh_last;
     const int n_dirty = dirty[0];
     if ((int)blockIdx.x >= n_dirty) return;
@@ -454,13 +550,11 @@ __global__ __launch_bounds__(256) void k_rows_eval(StreamArgs A, const double* _
     const int lp = i - A.gi0;
     if (lp < 0 || lp >= A.nloc) return;                     // another slab's row
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid < 225) ktab[tid] = ktab_g[tid];
-    __syncthreads();
     if (w == 0) {
         const int li = lp + 2;
-        const int nch = A.Pk > 256 ? (A.Pk >> 8) : 1;
+        const int jrow = (HW && lane >= 32) ? L_INACTIVE : j;       // the second half-wave idles
         auto rowp = [&](int d, int dj) { return A.cls + ((int64_t)(li + d) * A.RJ + (j + 2 + dj)) * A.pitchC + KOFFC; };
-        sweep_row<false>(A, ktab, rp, rowp, li, lp, j, A.gi0 + lp == A.L - 1, lane, nch);
+        sweep_row<TAB, HW>(A, rowp, li, lp, jrow, A.gi0 + lp == A.L - 1, lane);
     }
     __syncthreads();
     // the block that finishes a plane's last dirty row reduces that plane's three category blocks (waves 0..2);
@@ -477,6 +571,34 @@ __global__ __launch_bounds__(256) void k_rows_eval(StreamArgs A, const double* _
     __syncthreads();
     if (sh_last && w < 3) plane_reduce_wave<true>(A.rowsum, A.rowcnt, blocks, A.L, A.Pk, A.gi0, lp, w, lane);
 }
+
+// Per-voxel rate table (SlabView::vval) + plane L-1 deposition rates (dep_val) from the temperature field: run after
+// every temperature change (upload, thermal update) and parameter change, BEFORE k_interface (which then overwrites
+// the entries of the listed voxels with their interface sums).  Two voxels per thread; 16 B/voxel.
+__global__ __launch_bounds__(256) void k_rate_table(KParams P, SlabView S, double K0, const StepState* __restrict__ ss)
+{
+    if (ss && ss->status) return;          // terminated batch: T was passed through unchanged, the table stands
+    const int L = S.L, half = S.pitchT >> 1;
+    const int64_t n = (int64_t)S.nloc * L * half;
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = gtid; idx < n; idx += nthr) {
+        const int kp = (int)(idx % half);
+        const int64_t row = idx / half;                    // lp * L + j
+        const int64_t t = ((int64_t)2 * L + row) * S.pitchT + 2 * kp;       // local plane lp + 2
+        const double2 Tv = *reinterpret_cast<const double2*>(S.T + t);
+        double2 r;
+        r.x = nuc_bulk(P.T_melt, P.delta_T_c, P.kT, P.I0, P.rate_threshold, K0, Tv.x);
+        r.y = (2 * kp + 1 < L) ? nuc_bulk(P.T_melt, P.delta_T_c, P.kT, P.I0, P.rate_threshold, K0, Tv.y) : 0.0;
+        *reinterpret_cast<double2*>(S.vval + t) = r;
+    }
+    const int lp = L - 1 - S.gi0;                          // kmc_event_rates.py:59-63 for plane L-1
+    if (lp >= 0 && lp < S.nloc)
+        for (int64_t idx = gtid; idx < (int64_t)L * L; idx += nthr) {
+            const int j = (int)(idx / L), k = (int)(idx - (int64_t)j * L);
+            S.dep_val[(int64_t)j * S.pitchT + k] = dep_rate(P, pymax(S.T[S.tidx(lp + 2, j, k)], 1.0));
+        }
+}
+
 // k_plane_reduce: one wave per (owned plane, category): balanced tree over j of the row sums.
 __global__ __launch_bounds__(64) void k_plane_reduce(SlabView S, BlockEnt* __restrict__ blocks,
                                                      const StepState* __restrict__ ss)
@@ -583,12 +705,16 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
         ss->total = total; ss->n_events = n_events; ss->n_dep = n_dep;
         int go = info_only ? 0 : 1;
         if (!info_only) my_event->type = -1;
-        if (n_events == 0 || total < 1e-25 || !finite_d(total)) {
-            if (cfg.batch) ss->status = 1;
+        // reference stream: get_event_rates has drawn one species uniform per deposition candidate BEFORE run_kmc looks
+        // at the total (kmc_event_rates.py:65 precedes kmc_simulation.py:259-262), also on the step that terminates
+        const long long dep_draws = (cfg.batch && cfg.rng_mode == 0) ? n_dep : 0;
+        if (cfg.batch && go && np_pos0 + dep_draws > cfg.np_cap) {
+            ss->status = 2; go = 0;
+        } else if (n_events == 0 || total < 1e-25 || !finite_d(total)) {
+            if (cfg.batch) { ss->status = 1; ss->np_pos = np_pos0 + dep_draws; }
             go = 0;
         } else if (cfg.batch && go) {
-            long long need = (cfg.rng_mode == 0 ? n_dep : 0) + 2;
-            if (np_pos0 + need > cfg.np_cap) { ss->status = 2; go = 0; }
+            if (np_pos0 + dep_draws + 2 > cfg.np_cap) { ss->status = 2; go = 0; }
         }
         if (go) {
             const double r = cfg.batch ? u0 * total : r_direct;
@@ -631,7 +757,7 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
     __syncthreads();
     const int j = sh_j;
     // voxels of row (i, c, j): re-evaluate.  Interface voxels are all listed (invariant of the
-    // interface list) and k_interface has left their full EMPTY/DIFF category sum in ifc_val.
+    // interface list) and k_interface has left their full EMPTY/DIFF category sum in vval.
     for (int k = tid; k < Pk; k += 256) {
         double sum = 0.0; int cnt = 0;
         int maybe_ifc = 1;      // 0: certainly no interface voxel (its EMPTY category can only hold a nucleation)
@@ -641,7 +767,7 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
             const int st = S.state[S.sidx(li, j, k)];
             const bool listed = ifc_ready && S.ifc_in[t] != 0;
             maybe_ifc = (!ifc_ready || listed) ? 1 : 0;
-            const double v_ifc = S.ifc_val[t];
+            const double v_ifc = S.vval[t];
             const int c_ifc = S.ifc_cnt[t];
             const double Traw = S.T[t];
             if (c != CAT_DEP && listed) {
@@ -714,7 +840,7 @@ __global__ __launch_bounds__(256) void k_select(KParams P, const SlabView* __res
 // A voxel "owns interface events" iff it is empty with a W/Re/C neighbour (attachment) or a
 // W/Re/C atom with an empty neighbour (diffusion).  These are rare (a few per lattice row) and
 // expensive, so they are kept in a per-slab list (append-only superset, rebuilt at upload),
-// evaluated one voxel per lane by k_interface into ifc_val/ifc_cnt every step, and merely
+// evaluated one voxel per lane by k_interface into vval/ifc_cnt, and merely
 // looked up by the streaming sweep kernel.
 // Packed neighbourhood of a voxel: bits [2m+1:2m] describe neighbour slot m, bits [29:28] the voxel.
 //   empty voxel (own = 0): slot = species of a W/Re/C neighbour (1,2,3), 0 otherwise
@@ -848,7 +974,7 @@ __device__ __forceinline__ void ifc_eval_atom(const KParams& P, const SlabView& 
 // after an event changed voxel (i,j,k): it and its 14 neighbours may have become interface voxels,
 // and the category sums of those already listed are stale (their neighbour states / orientations
 // changed).  Called by a full wave: lane l < 15 handles one of the 15 voxels: append if needed, then
-// re-evaluate if listed -- this keeps ifc_val/ifc_cnt exact when k_interface ran BEFORE the event
+// re-evaluate if listed -- this keeps vval/ifc_cnt exact when k_interface ran BEFORE the event
 // (the speculative, overlapped launch of the batched loop).
 __device__ __forceinline__ void ifc_touch(const KParams& P, const SlabView& S, const double* ktab, int i, int j, int k, int lane,
                                           int eval)
@@ -876,18 +1002,8 @@ __device__ __forceinline__ void ifc_touch(const KParams& P, const SlabView& S, c
         int cnt = 0;
         if (st == 0) ifc_eval_empty(P, S, ktab, lp, aj, ak, t, code, Tc, sum, cnt);
         else if (st != 4) ifc_eval_atom(P, S, lp, aj, ak, t, code, st, Tc, sum, cnt);
-        S.ifc_val[t] = sum;
+        S.vval[t] = sum;
         S.ifc_cnt[t] = (uint8_t)cnt;
-    }
-}
-// deposition rates of plane L-1 as a function of temperature (every full sweep, by the interface kernels' threads)
-__device__ __forceinline__ void dep_fill(const KParams& P, const SlabView& S, int gtid, int nthreads)
-{
-    const int L = S.L, lp = L - 1 - S.gi0;
-    if (lp < 0 || lp >= S.nloc) return;
-    for (int idx = gtid; idx < L * L; idx += nthreads) {
-        const int j = idx / L, k = idx - j * L;
-        S.dep_val[(int64_t)j * S.pitchT + k] = dep_rate(P, pymax(S.T[S.tidx(lp + 2, j, k)], 1.0));
     }
 }
 // every step: EMPTY/DIFF category sum + count of every listed voxel, one voxel per lane.
@@ -913,10 +1029,9 @@ __global__ __launch_bounds__(256) void k_interface(KParams P, SlabView S, const 
         int cnt = 0;
         if (st == 0) ifc_eval_empty(P, S, ktab, lp, j, k, t, code, Tc, sum, cnt);
         else if (st != 4) ifc_eval_atom(P, S, lp, j, k, t, code, st, Tc, sum, cnt);
-        S.ifc_val[t] = sum;
+        S.vval[t] = sum;
         S.ifc_cnt[t] = (uint8_t)cnt;
     }
-    dep_fill(P, S, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 // Same results for long lists (Mode B, where most of the lattice becomes interface): a block takes tiles of
@@ -945,7 +1060,7 @@ __global__ __launch_bounds__(256) void k_interface_part(KParams P, SlabView S, c
                 const unsigned code = S.ifc_code[S.tidx((int)(v >> 20) + 2, (v >> 10) & 1023, v & 1023)];
                 if (code >> 30) {                                       // no events: result is zero
                     const int64_t t = S.tidx((int)(v >> 20) + 2, (v >> 10) & 1023, v & 1023);
-                    S.ifc_val[t] = 0.0; S.ifc_cnt[t] = 0;
+                    S.vval[t] = 0.0; S.ifc_cnt[t] = 0;
                 } else if (((code >> 28) & 3u) == 0) qe[atomicAdd(&ne, 1)] = v;
                 else qa[atomicAdd(&na, 1)] = v;
             }
@@ -964,11 +1079,10 @@ __global__ __launch_bounds__(256) void k_interface_part(KParams P, SlabView S, c
             int cnt = 0;
             if (is_e) ifc_eval_empty(P, S, ktab, lp, j, k, t, code, Tc, sum, cnt);
             else ifc_eval_atom(P, S, lp, j, k, t, code, (int)((code >> 28) & 3u), Tc, sum, cnt);
-            S.ifc_val[t] = sum;
+            S.vval[t] = sum;
             S.ifc_cnt[t] = (uint8_t)cnt;
         }
     }
-    dep_fill(P, S, blockIdx.x * 256 + tid, gridDim.x * 256);
 }
 
 // ---- apply -------------------------------------------------------------------------------
@@ -978,7 +1092,7 @@ __device__ __forceinline__ void write_site(const SlabView& S, int i, int j, int 
     if (li < 0 || li >= S.nloc + 4) return;
     S.state[S.sidx(li, j, k)] = (uint8_t)st;
     S.row_chg[(int64_t)li * S.L + j] = 1;
-    S.cls[S.cidx(li, j, k)] = class16(st);
+    S.cls[S.cidx(li, j, k)] = class8(st);
     const int64_t q = S.tidx(li, j, k);
     S.theta[q] = th; S.phi[q] = ph;
     orient_vec(th, ph, S.ovec + 3 * q);
@@ -1330,7 +1444,7 @@ __global__ void k_pack_u8(SlabView S, uint8_t* dst, const SRC* __restrict__ src,
         int li = i - (S.gi0 - 2);
         if (li < 0 || li >= S.nloc + 4) continue;
         dst[S.sidx(li, j, k)] = (uint8_t)src[idx];
-        if (with_cls) S.cls[S.cidx(li, j, k)] = class16((int)(uint8_t)src[idx]);
+        if (with_cls) S.cls[S.cidx(li, j, k)] = class8((int)(uint8_t)src[idx]);
     }
 }
 template <class DST>

@@ -18,6 +18,7 @@ struct SuperCfg {
     uint64_t seed;
     int32_t box, H, PH, PT;     // box edge, window edge (box/2), pow2(H), pow2(3H)
     int32_t nb;                 // boxes per axis
+    int32_t d0, D_loc;          // this handle's boxes: global indices [d0, d0 + D_loc) (box layers of its owned planes)
 };
 
 struct DomPick {          // result of the tree descent of one box
@@ -29,14 +30,15 @@ struct DomPick {          // result of the tree descent of one box
 };
 
 // One wave per box: leaves = category sums of the window's voxels, LDS heap of NL = PT*PH*PH leaves, descent.
-// Runs after a sweep launched with write-back (k_sweep_stream<.., true>): ifc_val/ifc_cnt then hold the
-// EMPTY- or DIFF-category sum of EVERY owned voxel, so a leaf is two loads (dep leaves: one exp, top plane only).
+// The per-voxel rate table (SlabView::vval) holds the EMPTY- or DIFF-category sum of EVERY owned voxel that owns events
+// (listed voxels: interface sums + ifc_cnt; other empty voxels: the nucleation rate by temperature), so a leaf is a
+// few loads (dep leaves: one exp, top plane only).
 __global__ __launch_bounds__(64) void k_domain_pick(KParams P, const SlabView* __restrict__ slabs, int nslabs, int L,
                                                     SuperCfg C, const StepState* __restrict__ ss, DomPick* __restrict__ picks)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
-    const int d = blockIdx.x;
+    const int d = C.d0 + blockIdx.x;            // global box index (keys the uniforms)
     if (ss->status) return;
     const int NL = C.PT * C.PH * C.PH;
     double* hs = reinterpret_cast<double*>(smem);             // [2*NL]
@@ -59,10 +61,14 @@ __global__ __launch_bounds__(64) void k_domain_pick(KParams P, const SlabView* _
         const int st = S.state[S.sidx(li, j, k)];
         const int64_t t = S.tidx(li, j, k);
         // value, count and membership flag are requested together with the state
-        const double val = S.ifc_val[t];
-        const int n_ev = S.ifc_cnt[t];
+        double val = S.vval[t];
+        int n_ev = S.ifc_cnt[t];
         const int listed = S.ifc_in[t] != 0;
         if (st >= 128 || st == 4) continue;
+        if (!listed) {          // not an interface voxel: an empty voxel owns at most its nucleation (the table entry), an atom nothing
+            if (st == 0) n_ev = (val != 0.0) ? 1 : 0;
+            else { val = 0.0; n_ev = 0; }
+        }
         const int c = (st == 0) ? CAT_EMPTY : CAT_DIFF;
         const int q = ((3 * ii + c) * C.PH + jj) * C.PH + kk;
         hs[NL + q] = val; hf[NL + q] = n_ev > 0; lc[q] = (uint8_t)(n_ev | (listed << 7));
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(64) void k_domain_pick(KParams P, const SlabView* _
         pk.rate = hs[NL + q];
         pk.simple = (lc[q] == 1 && pk.cat != CAT_DIFF) ? 1 : 0;     // one event, voxel not listed (or a deposition leaf)
     }
-    picks[d] = pk;
+    picks[blockIdx.x] = pk;
 }
 
 // One thread per box: slot scan inside the chosen voxel, uniforms, lattice write (kmc_simulation.py:276-327).
@@ -119,15 +125,16 @@ __global__ __launch_bounds__(64) void k_domain_slot_apply(KParams P, const SlabV
     for (int t = threadIdx.x; t < 225; t += 64) ktab[t] = ktab_g[t];
     __syncthreads();
     if (ss->status) return;
-    const int d = blockIdx.x * 64 + threadIdx.x;
-    if (d >= D) return;
+    const int dl = blockIdx.x * 64 + threadIdx.x;       // local box
+    if (dl >= D) return;
+    const int d = C.d0 + dl;                            // global box index (keys the uniforms)
     const int64_t g = C.step0 + ss->cur;
     cetkmc_event ev;
     ev.type = -1;
     ev.pos[0] = ev.pos[1] = ev.pos[2] = 0;
     ev.target[0] = ev.target[1] = ev.target[2] = -1;
     ev.atom = 0; ev.rate = 0.0; ev.dep_rank = -1; ev.theta = 0.0; ev.phi = 0.0;
-    const DomPick pk = picks[d];
+    const DomPick pk = picks[dl];
     if (pk.cat >= 0) {
         const int i = pk.i, j = pk.j, k = pk.k, c = pk.cat;
         const double r = pk.r;
@@ -170,13 +177,32 @@ __global__ __launch_bounds__(64) void k_domain_slot_apply(KParams P, const SlabV
             ev.phi = 0.0 + (6.283185307179586 - 0.0) * counter_uniform(C.seed, (uint64_t)g, KEY_PHI | (uint64_t)d);
         }
     }
-    dom_events[d] = ev;
-    if (log_events) log_events[ss->cur * (int64_t)D + d] = ev;
+    dom_events[dl] = ev;
+    if (log_events) log_events[ss->cur * (int64_t)D + dl] = ev;
     if (ev.type < 0) return;
     const int mk = (C.defect_fraction > 0.0 && counter_uniform(C.seed, (uint64_t)g, KEY_DEFECT | (uint64_t)d) < C.defect_fraction) ? 1 : 0;
     apply_event(slabs, nslabs, ev, mk);
     atomicAdd(&counters[0], 1ull);
     if (ev.type == EV_NUC) atomicAdd(&counters[1], 1ull);
+}
+
+// Across ranks: the events of the neighbour ranks' boundary box layers (nb^2 boxes each, received after their own
+// k_domain_slot_apply) applied to this rank's copy -- write_site() clips to the slab + halo, so owned planes receive
+// the diffusion targets that crossed the slab boundary and the halo planes stay a faithful copy of the neighbour.
+// recv[0 .. nb^2): layer below (global boxes d0 - nb^2 + q), recv[nb^2 .. 2 nb^2): layer above (d0 + D_loc + q').
+__global__ __launch_bounds__(64) void k_domain_apply_remote(const SlabView* __restrict__ slabs, int nslabs, SuperCfg C,
+                                                            const StepState* __restrict__ ss, const cetkmc_event* __restrict__ recv)
+{
+    if (ss->status) return;
+    const int nb2 = C.nb * C.nb;
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    if (q >= 2 * nb2) return;
+    const cetkmc_event ev = recv[q];
+    if (ev.type < 0) return;
+    const int d = (q < nb2) ? (C.d0 - nb2 + q) : (C.d0 + C.D_loc + (q - nb2));
+    const int64_t g = C.step0 + ss->cur;
+    const int mk = (C.defect_fraction > 0.0 && counter_uniform(C.seed, (uint64_t)g, KEY_DEFECT | (uint64_t)d) < C.defect_fraction) ? 1 : 0;
+    apply_event(slabs, nslabs, ev, mk);
 }
 
 // Interface upkeep for the touched voxels, after ALL lattice writes of the super-step.  8 boxes per 256-thread
@@ -222,7 +248,7 @@ __global__ __launch_bounds__(256) CETKMC_TOUCH_ATTR void k_domain_touch(KParams 
         int cnt = 0;
         if (st == 0) ifc_eval_empty(P, S, ktab, lp, aj, ak, t, code, Tc, sum, cnt);
         else if (st != 4) ifc_eval_atom(P, S, lp, aj, ak, t, code, st, Tc, sum, cnt);
-        S.ifc_val[t] = sum;
+        S.vval[t] = sum;
         S.ifc_cnt[t] = (uint8_t)cnt;
     }
 }

@@ -12,19 +12,19 @@ namespace cetkmc {
 
 constexpr int KOFF = 4;           // byte offset of k=0 inside a padded state row
 constexpr uint8_t OOB = 255;      // sentinel state outside the lattice
-constexpr int KOFFC = 4;          // u16 offset of k=0 inside a padded class row
+constexpr int KOFFC = 8;          // byte offset of k=0 inside a padded class row (8: a lane's 8 voxels are one aligned b64)
 
-// Census class of a lattice state: four 4-bit counters-to-be.  Summing the class words of the
-// 14 neighbours gives, without any compare, [3:0] #in-bounds, [7:4] #empty, [11:8] #W/Re/C
-// (attachment sources), [15:12] #Re/C (nucleation impurities).  Out-of-lattice = 0.
-__host__ __device__ inline uint16_t class16(int st)
+// Census class of a lattice state, one byte per voxel: bit 0 = empty, bit 1 = W/Re/C (an attachment source /
+// a diffusing atom); defects (4) and everything outside the lattice are 0.  OR-ing the class bytes of the 14
+// neighbours answers the two questions the rate sweep asks of a neighbourhood -- "any W/Re/C neighbour?" (the voxel
+// owns attachment events: it is an interface voxel) and "any empty neighbour?" (an atom owns diffusion events) --
+// without a compare; the neighbour COUNTS of the rate formulas (kmc_event_rates.py:95-101,121-125) are only needed at
+// interface voxels, whose packed neighbourhood word (ifc_encode) carries them.
+__host__ __device__ inline uint8_t class8(int st)
 {
-    if (st >= 128) return 0;
-    uint16_t c = 0x0001;
-    if (st == 0) c |= 0x0010;
-    if (st >= 1 && st <= 3) c |= 0x0100;
-    if (st == 2 || st == 3) c |= 0x1000;
-    return c;
+    if (st == 0) return 0x01;
+    if (st >= 1 && st <= 3) return 0x02;
+    return 0;
 }
 constexpr int CAT_DEP = 0, CAT_DIFF = 1, CAT_EMPTY = 2;
 constexpr int EV_DEP = 0, EV_DIFF = 1, EV_NUC = 2, EV_ATT = 3;
@@ -53,12 +53,12 @@ struct SlabView {
     int pitchS;   // bytes per padded state row (k=0 at KOFF)
     int pitchT;   // doubles per T/theta/phi row
     int Pk;       // next_pow2(L)
-    int pitchC;   // u16 elements per padded class row (k=0 at KOFFC)
+    int pitchC;   // bytes per padded class row (k=0 at KOFFC; >= KOFFC + L + 12 so that a lane may read 4 bytes past its 8)
     uint8_t* state;     // [(nloc+4)][RJ][pitchS]
     uint8_t* defects;   // same layout
     uint8_t* row_chg;   // [(nloc+4)][L]: 1 if a voxel of row (li, j) was written since prev_state was last brought level with
                         // state (the latent-heat test of the temperature update only looks at such rows)
-    uint16_t* cls;      // [(nloc+4)][RJ][pitchC] neighbour-census class of every voxel (class16())
+    uint8_t* cls;       // [(nloc+4)][RJ][pitchC] neighbour-census class of every voxel (class8())
     double* T;          // [(nloc+4)][L][pitchT]  (current buffer)
     double* theta;
     double* phi;
@@ -66,10 +66,14 @@ struct SlabView {
     double* rowsum;     // [nloc*3][L]  row sums of the last sweep, index (lp*3+cat)*L + j
     int32_t* rowcnt;
     // interface voxels (voxels owning attachment / diffusion events), see k_interface:
-    double* ifc_val;    // [(nloc+4)][L][pitchT] EMPTY- or DIFF-category sum of an interface voxel (tidx)
+    double* vval;       // [(nloc+4)][L][pitchT] (tidx) per-voxel rate table: the EMPTY-category sum of an empty voxel / the
+                        // DIFF-category sum of an atom.  Listed (interface) voxels: written by k_interface / ifc_touch /
+                        // k_domain_touch whenever their neighbourhood or T changes.  All other voxels: the nucleation rate
+                        // of an empty voxel WITHOUT W/Re/C neighbours at its temperature (K_eff = K_nuc for every neighbour
+                        // count, kmc_event_rates.py:122-130), written by k_rate_table after every temperature change.
     double* dep_val;    // [L][pitchT] deposition rate of every (j,k) of plane L-1 from its T alone (kmc_event_rates.py:59-63;
-                        // emptiness is tested by the reader); refreshed by k_interface*; used iff the slab owns plane L-1
-    uint8_t* ifc_cnt;   // same indexing: its event count
+                        // emptiness is tested by the reader); refreshed by k_rate_table; used iff the slab owns plane L-1
+    uint8_t* ifc_cnt;   // same indexing: event count of a LISTED voxel (others: vval != 0 ? 1 : 0 for an empty voxel)
     uint8_t* ifc_in;    // same indexing: 1 if the voxel is in ifc_list
     uint32_t* ifc_code; // same indexing: packed neighbourhood of a listed voxel (ifc_encode), kept current by apply
     uint32_t* ifc_list; // packed (lp << 20 | j << 10 | k) of the listed voxels (append-only, superset)

@@ -46,20 +46,31 @@ def introduce_defects(state, atom_type, T=None, apply_to_state=False, voxel_size
     return mask, get_defect_density(mask, voxel_size)
 
 
-def refresh_defects_device(engine):
+def refresh_defects_device(engine, rank_counts=None, rank=0):
     """introduce_defects(state, atom_type, T) for the lattice resident on the GPU without moving the
     lattice: only the carbon sites (index + T) come to the host, the Bernoulli draws are taken from
     NumPy's global stream in row-major site order exactly as track_defects does (defects.py:8-18), and
-    only the flagged indices go back.  Returns (number of flagged sites, density)."""
+    only the flagged indices go back.  Returns (number of flagged sites, density).
+
+    Across ranks (axis-0 slabs, one engine per rank): ``rank_counts(n_mine)`` returns every rank's site count
+    (an all-gather); the global row-major site order is the concatenation of the ranks' orders, so each rank
+    draws the whole stream -- every rank holds the same generator state -- and keeps its own slice.  The
+    returned count / density are then this rank's share."""
     idx, t_here = engine.gather_species(_C_SITE)
     L = engine.L
+    n_before, n_total = 0, len(idx)
+    if rank_counts is not None:
+        counts = list(rank_counts(len(idx)))
+        n_before, n_total = int(sum(counts[:rank])), int(sum(counts))
     flagged = np.zeros(0, dtype=np.int64)
-    if len(idx):
-        with np.errstate(divide="ignore", invalid="ignore"):
-            t_here = np.where(t_here > 0, t_here, T_SUB)
-            p = DEFECT_PROB_BASE * np.exp(-0.3 / (K_T * t_here))
-        p = np.clip(p, 0.0, 1.0)
-        flagged = idx[np.random.random(len(idx)) < p]
+    if n_total:
+        u = np.random.random(n_total)[n_before:n_before + len(idx)]
+        if len(idx):
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t_here = np.where(t_here > 0, t_here, T_SUB)
+                p = DEFECT_PROB_BASE * np.exp(-0.3 / (K_T * t_here))
+            p = np.clip(p, 0.0, 1.0)
+            flagged = idx[u < p]
     engine.set_defects_sparse(flagged)
     volume = (L ** 3) * (5e-6 ** 3)
     return int(len(flagged)), (len(flagged) / volume if volume > 0 else 0.0)

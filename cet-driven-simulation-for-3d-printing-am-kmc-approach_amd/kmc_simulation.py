@@ -43,9 +43,18 @@ def _advance_to(engine, first, last, L, defect_fraction, rng_mode=0, seed=0, inc
     terminated = False
     last_total = 0.0
     per = 3 if defect_fraction > 0.0 else 2
+    slack = 8
     while step <= last:
         n = last - step + 1
-        per_step = (L * L + 2) if rng_mode == 0 else 2
+        if rng_mode == 0:
+            # One deposition-species draw per finite-rate deposition candidate per step (kmc_event_rates.py:63-65) + 2
+            # orientation draws.  The candidate count is asked from the device (one sweep) instead of assuming the
+            # whole top plane (L*L): at L = 256 that assumption means ~13 M doubles drawn, uploaded and re-drawn per
+            # 200-step batch.  A batch that still runs short stops with status 2 and is continued from there.
+            n_dep_now = int(engine.rate_sweep()[2])
+            per_step = min(L * L, n_dep_now + slack) + 2
+        else:
+            per_step = 2
         n = max(1, min(n, _MAX_STREAM_DOUBLES // per_step))
         py_state = random.getstate()
         draws = np.array([random.random() for _ in range(per * n)], dtype=np.float64).reshape(n, per)
@@ -72,7 +81,9 @@ def _advance_to(engine, first, last, L, defect_fraction, rng_mode=0, seed=0, inc
             last_total = float(res["totals"][done]) if len(res["totals"]) > done else 0.0
             break
         if res["status"] == 2 and done == 0:
-            raise RuntimeError("pre-drawn NumPy stream too small for a single step")
+            if slack >= L * L:
+                raise RuntimeError("pre-drawn NumPy stream too small for a single step")
+            slack = min(L * L, 4 * slack + 64)       # the estimate was short (candidates appeared): widen and retry
     return step - first, terminated, last_total, dts
 
 
@@ -83,13 +94,15 @@ def save_checkpoint(path, fields, defects_mask, next_step, total_time, nucleatio
     import json
     py = random.getstate()
     npst = np.random.get_state()
+    tmp = path + ".tmp.npz"        # written beside the target and renamed into place: a crash mid-write keeps the old file
     np.savez_compressed(
-        path, state=fields["state"].astype(np.int8), theta=fields["theta"], phi=fields["phi"], T=fields["T"],
+        tmp, state=fields["state"].astype(np.int8), theta=fields["theta"], phi=fields["phi"], T=fields["T"],
         defects=np.asarray(defects_mask).astype(np.int8), next_step=next_step, total_time=total_time,
         nucleation_count=nucleation_count, cet_detected=bool(cet_detected),
         py_version=py[0], py_mt=np.array(py[1], dtype=np.uint64), py_gauss=np.array([np.nan if py[2] is None else py[2]]),
         np_mt=npst[1], np_pos=npst[2], np_has_gauss=npst[3], np_cached=npst[4],
         metrics_json=np.array(json.dumps(metrics_data, default=lambda o: o.item() if hasattr(o, "item") else str(o))))
+    os.replace(tmp, path)
 
 
 def load_checkpoint(path):

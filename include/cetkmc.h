@@ -138,8 +138,9 @@ typedef struct cetkmc_super_args {
 } cetkmc_super_args;
 
 /* Work issued, bytes moved and (while cetkmc_run_args.profile == 2) device time per phase, accumulated on the
- * handle since creation / the last reset.  Algorithmic bytes: 10 B per owned voxel per rate sweep (class u16 +
- * T f64), 16 B per owned voxel per temperature update. */
+ * handle since creation / the last reset.  Algorithmic bytes: 9 B per owned voxel per rate sweep (class u8 + rate
+ * table f64; the recompute variant streams T f64 instead), 16 B per owned voxel per temperature update and 16 B per
+ * owned voxel per rate-table refresh (T read, entry written). */
 typedef struct cetkmc_counters {
     int64_t steps;              /* batched Mode A steps executed (cetkmc_run_steps)               */
     int64_t sweeps;             /* full rate sweeps launched (any entry point)                     */
@@ -149,7 +150,10 @@ typedef struct cetkmc_counters {
     int64_t bytes_h2d, bytes_d2h;               /* host <-> device bytes moved by this handle       */
     int64_t alg_bytes_sweep, alg_bytes_thermal; /* algorithmic bytes of the work issued             */
     int64_t profiled_steps;     /* steps the ms_* fields below cover                               */
-    double  ms_thermal, ms_interface, ms_sweep, ms_dirty_rows, ms_reduce, ms_select_apply;
+    double  ms_thermal, ms_interface /* rate table + interface list kernels */, ms_sweep, ms_dirty_rows, ms_reduce, ms_select_apply;
+    int64_t alg_bytes_table;    /* rate-table refreshes (k_rate_table)                             */
+    int64_t table_updates;      /* rate-table refreshes launched                                   */
+    int64_t interface_launches; /* full interface-list evaluations launched                        */
 } cetkmc_counters;
 
 const char* cetkmc_last_error(void);
@@ -185,7 +189,10 @@ int cetkmc_create_rank_host(const cetkmc_params* p, int L, int rank, int nranks,
 int cetkmc_destroy(void* handle);
 int cetkmc_set_params(void* handle, const cetkmc_params* p);
 int cetkmc_sync(void* handle);
-/* tuning / A-B switches: "sweep_variant" 0 = simple kernel, 1 = queued interface events (default) */
+/* tuning / A-B switches: "sweep_variant" 0 = simple kernel, 1 = streaming kernel + per-voxel rate table (default),
+ * 2 = streaming kernel that recomputes the nucleation rates in every sweep; "interface_every_step" 1 = evaluate the
+ * whole interface list before every full sweep instead of only after a temperature update; "thermal_variant",
+ * "thermal_planes_per_block" */
 int cetkmc_set_option(void* handle, const char* key, int64_t value);
 /* planes [*i0,*i1) owned by this handle (whole lattice unless created with create_rank) */
 int cetkmc_owned_planes(void* handle, int* i0, int* i1);
@@ -237,7 +244,13 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* args, cetkmc_run_resul
                      double* totals, cetkmc_event* events, int64_t* n_events);
 
 /* totals[n] (Mode A total of every super-step's sweep), events[n][D] or NULL (type -1: idle box),
- * n_executed[n] events applied per super-step.  res->np_used is 0; single process only. */
+ * n_executed[n] events applied per super-step.  res->np_used is 0.
+ * Across ranks (cetkmc_create_rank*; needs (L / nranks) % box == 0): the boxes are sharded with the slabs -- D is the
+ * number of THIS rank's boxes ((L / nranks / box) * (L / box)^2, global box order = rank order), events / n_executed /
+ * res->nucleation_count cover this rank's boxes only (the caller sums them), totals are global.  Per super-step the
+ * ranks exchange the block sums (all-gather, as Mode A) and the events of their boundary box layers (neighbour
+ * send/recv, (L/box)^2 records each way): every rank applies its neighbours' boundary events to its own copy of the
+ * halo planes and of the owned planes a diffusion target reached. */
 int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_result* res, double* totals,
                           cetkmc_event* events, int64_t* n_executed);
 

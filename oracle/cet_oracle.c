@@ -592,9 +592,14 @@ int64_t orc_run_steps(const orc_params *P, int L, int8_t *state, double *theta, 
         orc_block_sums(L, rowsum, rowcnt, 0, L, blocksum, blockcnt);
         int64_t ne = 0, nd = 0;
         double total = orc_total(L, blocksum, blockcnt, &ne, &nd);
-        if (ne == 0 || total < 1e-25 || !isfinite(total)) { *status = 1; totals[s] = total; break; }
-        int64_t need = (rng_mode == 0 ? nd : 0) + 2;
-        if (pos + need > np_cap) { *status = 2; break; }
+        /* get_event_rates has already drawn one species uniform per deposition candidate when run_kmc looks at the
+         * total (kmc_event_rates.py:65 precedes kmc_simulation.py:259-262): also on the terminating step.  Parity
+         * unpinned for that step: run_kmc cannot reach a termination with candidates left (T >= T_SUB after the first
+         * update keeps every empty site's nucleation rate large), so no reference fixture covers it. */
+        const int64_t dep_draws = (rng_mode == 0) ? nd : 0;
+        if (pos + dep_draws > np_cap) { *status = 2; break; }
+        if (ne == 0 || total < 1e-25 || !isfinite(total)) { *status = 1; totals[s] = total; pos += dep_draws; break; }
+        if (pos + dep_draws + 2 > np_cap) { *status = 2; break; }
         orc_event ev;
         orc_select_tree(P, L, state, theta, phi, T, defects, blocksum, blockcnt, rowsum, rowcnt,
                         u_pick[s] * total, &ev);
@@ -697,6 +702,21 @@ static int window_select(const orc_params *P, int L, const int8_t *state, const 
     ev->atom = S.atom[pick];
     ev->dep_rank = -1;
     return 0;
+}
+
+/* one box's pick on the given lattice copy (window origin i0,j0,k0, edge H, uniform u): exported for the multi-rank
+ * protocol rehearsal (tests/test_dist_gloo.py), where every rank picks for its own boxes on its slab + halo copy.
+ * Returns 1 for an idle box (ev->type == -1). */
+int orc_window_pick(const orc_params *P, int L, const int8_t *state, const double *theta, const double *phi,
+                    const double *T, const int8_t *defects, int i0, int j0, int k0, int H, double u, orc_event *ev)
+{
+    const int PH = next_pow2(H), PT = next_pow2(3 * H);
+    const int64_t NL = (int64_t)PT * PH * PH;
+    double *leaf = (double *)malloc(sizeof(double) * (size_t)NL);
+    int32_t *lcnt = (int32_t *)malloc(sizeof(int32_t) * (size_t)NL);
+    const int idle = window_select(P, L, state, theta, phi, T, defects, i0, j0, k0, H, u, leaf, lcnt, ev);
+    free(leaf); free(lcnt);
+    return idle;
 }
 
 int64_t orc_run_supersteps(const orc_params *P, int L, int8_t *state, double *theta, double *phi,

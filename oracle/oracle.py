@@ -203,6 +203,13 @@ class Lattice:
                                    C.c_double(r), C.byref(ev))
         return None if rc else ev
 
+    def window_pick(self, i0, j0, k0, H, u):
+        """Mode B: the pick of ONE box (window origin, edge H, uniform u) on this lattice copy; None for an idle box."""
+        ev = Event()
+        idle = lib().orc_window_pick(C.byref(self.params), self.L, *self._fields(), int(i0), int(j0), int(k0), int(H),
+                                     C.c_double(u), C.byref(ev))
+        return None if idle else ev
+
     def sweep(self):
         rs, rc = self.row_sums()
         bs, bc = self.block_sums(rs, rc)

@@ -188,3 +188,130 @@ def test_slab_protocol_world(oracle_mod, tmp_path, L, world):
         assert np.array_equal(z["log"][:, 0], res["events"]["type"])
         assert np.array_equal(z["log"][:, 1:4], res["events"]["pos"])
         assert np.array_equal(z["log"][:, -1], res["totals"])      # bit-identical totals on every rank
+
+
+# ---- Mode B (super-steps) across ranks: boxes sharded with the slabs, boundary box layers' events exchanged ----------
+KEY_PICK, KEY_THETA, KEY_PHI, KEY_DEFECT = 1 << 40, 2 << 40, 3 << 40, 4 << 40
+
+
+def _worker_b(rank, world, port, L, box, n_steps, seed, df, out_dir):
+    """Protocol of cetkmc_run_supersteps across ranks (cetkmc_hip.hip), with the CPU oracle as the per-slab engine:
+    per super-step (1) own row/block sums, all-gather, global total; (2) every rank picks for ITS boxes on its
+    slab + halo copy; (3) the events of the bottom / top box layer go to the rank below / above (neighbour
+    send/recv), records carry species and orientation; (4) own and received events are applied, writes clipped
+    to slab + halo.  Everything outside slab + halo is poisoned."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle
+    state, theta, phi, T, defects = random_lattice(L, seed, fill=0.25)
+    i0, i1 = _slab(L, rank, world)
+    a, b = max(0, i0 - 2), min(L, i1 + 2)
+    rs = np.random.RandomState(1000 + rank)
+    poison = np.ones(L, bool)
+    poison[a:b] = False
+    state = state.copy(); theta = theta.copy(); phi = phi.copy(); T = T.copy()
+    state[poison] = rs.randint(0, 5, state[poison].shape)
+    theta[poison] = 99.0
+    phi[poison] = -99.0
+    T[poison] = np.nan
+    lat = oracle.Lattice(state, theta, phi, T, defects, impurity_c=0.2)
+    nb, H = L // box, box // 2
+    nb2 = nb * nb
+    d0, D = (i0 // box) * nb2, ((i1 - i0) // box) * nb2
+    rowsum = np.zeros((L, 3, L)); rowcnt = np.zeros((L, 3, L), np.int32)
+    log, totals, n_exec = [], [], []
+    for g in range(n_steps):
+        lat.row_sums(i0, i1, rowsum, rowcnt)
+        bs = np.zeros(3 * L); bc = np.zeros(3 * L, np.int64)
+        lat.block_sums(rowsum, rowcnt, i0, i1, bs, bc)
+        mine = torch.from_numpy(np.concatenate([bs[3 * i0:3 * i1], bc[3 * i0:3 * i1].astype(np.float64)]))
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        for r_, gt in enumerate(gathered):
+            j0_, j1_ = _slab(L, r_, world)
+            gt = gt.numpy(); n = 3 * (j1_ - j0_)
+            bs[3 * j0_:3 * j1_] = gt[:n]; bc[3 * j0_:3 * j1_] = gt[n:].astype(np.int64)
+        total, n_events, _ = lat.total(bs, bc)
+        totals.append(total)
+        assert n_events > 0
+        sec = g % 8
+        si, sj, sk = (sec >> 2) & 1, (sec >> 1) & 1, sec & 1
+        recs = np.zeros((D, 12))                       # valid, type, pos3, target3, atom, theta, phi, make_defect
+        for dl in range(D):
+            d = d0 + dl
+            di, dj, dk = d // nb2, (d // nb) % nb, d % nb
+            ev = lat.window_pick(di * box + si * H, dj * box + sj * H, dk * box + sk * H, H,
+                                 oracle.counter_uniform(seed, g, KEY_PICK | d))
+            if ev is None:
+                continue
+            atom, th, ph = ev.atom, 0.0, 0.0
+            if ev.type == 0:
+                u = oracle.counter_uniform(seed, g, ev.pos[1] * L + ev.pos[2])
+                atom = 3 if u < 0.2 else (2 if u < 0.2 + 0.10 else 1)
+            if ev.type in (0, 2):
+                th = np.pi * oracle.counter_uniform(seed, g, KEY_THETA | d)
+                ph = 2 * np.pi * oracle.counter_uniform(seed, g, KEY_PHI | d)
+            else:               # diff moves the source's orientation, att copies the neighbour's
+                src = tuple(ev.pos) if ev.type == 1 else tuple(ev.target)
+                th, ph = lat.theta[src], lat.phi[src]
+            mk = df > 0.0 and oracle.counter_uniform(seed, g, KEY_DEFECT | d) < df
+            recs[dl] = [1, ev.type, *ev.pos, *ev.target, atom, th, ph, mk]
+        # boundary box layers to the neighbours (== ncclSend/ncclRecv of (L/box)^2 event records each way)
+        reqs, lo, hi = [], None, None
+        if rank > 0:
+            reqs.append(dist.isend(torch.from_numpy(recs[:nb2].copy()), rank - 1))
+            lo = torch.empty((nb2, 12), dtype=torch.float64); reqs.append(dist.irecv(lo, rank - 1))
+        if rank < world - 1:
+            reqs.append(dist.isend(torch.from_numpy(recs[D - nb2:].copy()), rank + 1))
+            hi = torch.empty((nb2, 12), dtype=torch.float64); reqs.append(dist.irecv(hi, rank + 1))
+        for r_ in reqs:
+            r_.wait()
+        todo = [recs] + [x.numpy() for x in (lo, hi) if x is not None]
+
+        def put(ijk, st, t_, p_):                                    # write_site(): only inside slab+halo
+            if a <= ijk[0] < b:
+                lat.state[ijk] = st; lat.theta[ijk] = t_; lat.phi[ijk] = p_
+        for block in todo:
+            for v in block:
+                if v[0] != 1:
+                    continue
+                typ, pos, tgt, atom = int(v[1]), tuple(int(x) for x in v[2:5]), tuple(int(x) for x in v[5:8]), int(v[8])
+                upd = pos
+                if typ in (0, 2, 3):
+                    put(pos, atom, v[9], v[10])
+                else:
+                    put(tgt, atom, v[9], v[10])
+                    put(pos, 0, 0.0, 0.0)
+                    upd = tgt
+                if v[11]:
+                    put(upd, 4, 0.0, 0.0)
+        n_exec.append(int(recs[:, 0].sum()))
+        log.append(recs[:, :9].copy())
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), state=lat.state[i0:i1], theta=lat.theta[i0:i1], phi=lat.phi[i0:i1],
+             log=np.array(log), totals=np.array(totals), n_exec=np.array(n_exec))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("L,world,box", [(16, 2, 8), (24, 3, 8)])
+def test_mode_b_slab_protocol_world(oracle_mod, tmp_path, L, world, box):
+    n_steps, seed, df = 20, 11, 0.05
+    mp.spawn(_worker_b, args=(world, _free_port(), L, box, n_steps, seed, df, str(tmp_path)), nprocs=world, join=True)
+    state, theta, phi, T, defects = random_lattice(L, seed, fill=0.25)
+    lat = oracle_mod.Lattice(state, theta, phi, T, defects, impurity_c=0.2)
+    res = lat.run_supersteps(0, n_steps, box, df, seed, thermal_mode=0)
+    assert res["done"] == n_steps
+    zs = [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]
+    log = np.concatenate([z["log"] for z in zs], axis=1)             # [n][D global][9]
+    live = log[:, :, 0] == 1
+    assert np.array_equal(live, res["events"]["type"] >= 0)
+    assert np.array_equal(log[:, :, 1][live], res["events"]["type"][live])
+    assert np.array_equal(log[:, :, 2:5][live], res["events"]["pos"][live])
+    assert np.array_equal(log[:, :, 5:8][live], res["events"]["target"][live])
+    assert np.array_equal(log[:, :, 8][live], res["events"]["atom"][live])
+    assert np.array_equal(sum(z["n_exec"] for z in zs), res["n_exec"])
+    for rank, z in enumerate(zs):
+        i0, i1 = _slab(L, rank, world)
+        assert np.array_equal(z["totals"], res["totals"])
+        assert np.array_equal(z["state"], lat.state[i0:i1])
+        assert np.array_equal(z["theta"], lat.theta[i0:i1]) and np.array_equal(z["phi"], lat.phi[i0:i1])

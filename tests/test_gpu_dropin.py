@@ -124,7 +124,7 @@ def test_rccl_single_rank_mode():
         else:
             e = cetkmc.Engine(L, impurity_c=0.2, rank=0, nranks=1, unique_id=cetkmc.Engine.unique_id())
         if mode == "rank+overlap":
-            e.set_option("overlap_interface", 1)
+            e.set_option("interface_every_step", 1)
         e.upload(state, theta, phi, T, defects)
         res = e.run_steps(0, n, 0.05, u_pick, u_def, u_np, rng_mode=0, thermal_mode=1, incremental=(mode == "rank+incremental"))
         outs.append((res["totals"].copy(), res["events"].tobytes(), e.download()))

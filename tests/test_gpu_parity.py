@@ -87,20 +87,22 @@ def test_sweep_vs_oracle_larger(oracle_mod, L, seed):
 
 @pytest.mark.parametrize("L,seed,fill", [(24, 1, 0.3), (40, 2, 0.05), (70, 3, 0.5), (8, 4, 0.9)])
 def test_sweep_variants_bit_identical(L, seed, fill):
-    """The streaming kernel (+ interface list) and the simple kernel produce identical row sums,
-    also after events were applied (incremental interface-list maintenance)."""
+    """The streaming kernel with the per-voxel rate table (1), the streaming kernel that recomputes the nucleation
+    rates per sweep (2) and the simple kernel (0) produce identical row sums, also after events were applied
+    (interface-list / rate-table maintenance by the apply kernel)."""
     state, theta, phi, T, defects = random_lattice(L, seed, fill=fill)
     e = _engine(L, 0.2)
     e.upload(state, theta, phi, T, defects)
     rs = np.random.RandomState(seed)
     for rnd in range(3):
         out = []
-        for v in (1, 0):
+        for v in (1, 2, 0):
             e.set_option("sweep_variant", v)
             info = e.rate_sweep()
             out.append((info,) + e.row_sums())
-        assert out[0][0] == out[1][0]
-        assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+        for o in out[1:]:
+            assert out[0][0] == o[0]
+            assert np.array_equal(out[0][1], o[1]) and np.array_equal(out[0][2], o[2])
         e.set_option("sweep_variant", 1)
         n = 25
         res = e.run_steps(rnd * n, n, 0.1, rs.random_sample(n), rs.random_sample(n), rs.random_sample(n * (L * L + 2)),
@@ -421,7 +423,7 @@ def test_large_L_two_chunks_per_row(L):
     q = synthetic.laser_planes(L, 0, n)
     u_pick, u_def, u_np = rs.random_sample(n), rs.random_sample(n), rs.random_sample(2 * n + 2)
     outs = []
-    for ns, variant in ((1, 1), (1, 0), (3, 1)):
+    for ns, variant in ((1, 1), (1, 0), (3, 1), (2, 2)):
         e = cetkmc.Engine(L, impurity_c=0.2, n_slabs=ns)
         e.set_option("sweep_variant", variant)
         e.upload_planes(0, L, st, th, ph, T, df)
@@ -432,12 +434,13 @@ def test_large_L_two_chunks_per_row(L):
         assert r["done"] == n
         outs.append((info, rsum.tobytes(), rcnt.tobytes(), r["totals"].tobytes(), r["events"].tobytes()))
         e.close()
-    assert outs[0] == outs[1] and outs[0] == outs[2]
+    assert outs[0] == outs[1] and outs[0] == outs[2] and outs[0] == outs[3]
 
 
-def test_overlapped_interface_option_identical():
-    """overlap_interface=1 (speculative k_interface on a second stream + re-evaluation of the touched
-    voxels inside the apply kernel) must not change a single bit."""
+def test_interface_every_step_option_identical():
+    """Default: the interface list is evaluated in full only after a temperature update, in between the apply
+    kernel re-evaluates the <= 30 listed voxels an event touches.  interface_every_step=1 (the whole list before
+    every full sweep) must not change a single bit."""
     L = 40
     state, theta, phi, T, defects = random_lattice(L, 31, fill=0.2)
     rs = np.random.RandomState(8)
@@ -446,7 +449,7 @@ def test_overlapped_interface_option_identical():
     outs = []
     for ov in (0, 1):
         e = _engine(L, 0.2)
-        e.set_option("overlap_interface", ov)
+        e.set_option("interface_every_step", ov)
         e.upload(state, theta, phi, T, defects)
         res = e.run_steps(0, n, 0.05, u_pick, u_def, u_np, rng_mode=0, thermal_mode=1)
         assert res["done"] == n
@@ -455,21 +458,32 @@ def test_overlapped_interface_option_identical():
     assert outs[0] == outs[1]
 
 
-@pytest.mark.parametrize("L", [36, 264])
-def test_stream_kernel_four_row_blocks(L, monkeypatch):
-    """The 4-rows-per-block instantiation of the streaming kernel (picked automatically for L >= ~300,
-    i.e. the multi-GPU bench sizes) equals the simple kernel bit for bit."""
+@pytest.mark.parametrize("L", [36, 255, 264, 520])
+def test_stream_kernel_row_shapes(L):
+    """Rows of <= 256 voxels occupy half a wave (two rows per wave), longer rows one or two 512-voxel chunks of a
+    full wave; ragged L leaves the last lane partly outside the lattice.  Both streaming variants equal the simple
+    kernel bit for bit."""
     import cetkmc
-    monkeypatch.setenv("CETKMC_STREAM_TJ", "4")
-    state, theta, phi, T, defects = random_lattice(L, 77, fill=0.15 if L < 100 else 0.02)
     e = cetkmc.Engine(L, impurity_c=0.2)
-    e.upload(state, theta, phi, T, defects)
+    if L < 400:
+        state, theta, phi, T, defects = random_lattice(L, 77, fill=0.15 if L < 100 else 0.02)
+        e.upload(state, theta, phi, T, defects)
+    else:               # narrow host arrays (u8 state): 520^3 in the reference's int64 would be 1.1 GB per field
+        from cetkmc import synthetic
+        st, th, ph, T, df = synthetic.planes(L, 0, L, seed=3)
+        idx = np.random.RandomState(9).randint(0, L, (20000, 3))
+        st[idx[:, 0], idx[:, 1], idx[:, 2]] = np.random.RandomState(10).randint(1, 5, 20000)
+        e.upload_planes(0, L, st, th, ph, T, df)
+        e.set_prev_state(None)
+        del st, th, ph, T, df
     out = []
-    for v in (1, 0):
+    for v in (1, 2, 0):
         e.set_option("sweep_variant", v)
         out.append((e.rate_sweep(),) + e.row_sums())
-    assert out[0][0] == out[1][0]
-    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    for o in out[1:]:
+        assert out[0][0] == o[0]
+        assert np.array_equal(out[0][1], o[1]) and np.array_equal(out[0][2], o[2])
+    e.close()
 
 
 @pytest.mark.parametrize("L,fill,n_slabs,thermal", [(20, 0.25, 1, 1), (40, 0.2, 3, 1), (33, 0.6, 1, 0), (70, 0.1, 2, 1)])
@@ -539,7 +553,9 @@ def test_counters_and_phase_profile():
         c = e.counters()
         assert r["done"] == n and c["steps"] == n and c["thermal_updates"] == 3
         assert c["sweeps"] == (n if not inc else 3) and c["incremental_steps"] == (0 if not inc else n - 3)
-        assert c["alg_bytes_sweep"] == c["sweeps"] * 10 * L ** 3 and c["alg_bytes_thermal"] == 3 * 16 * L ** 3
+        assert c["alg_bytes_sweep"] == c["sweeps"] * 9 * L ** 3 and c["alg_bytes_thermal"] == 3 * 16 * L ** 3
+        # rate table + full interface-list evaluation only after the three temperature updates
+        assert c["table_updates"] == 3 and c["alg_bytes_table"] == 3 * 16 * L ** 3 and c["interface_launches"] == 3
         if prof == 2:
             assert c["profiled_steps"] == n
             assert c["ms_sweep"] > 0 and c["ms_interface"] > 0 and c["ms_select_apply"] > 0 and c["ms_thermal"] > 0
