@@ -213,8 +213,7 @@ int create_common(const cetkmc_params* p, int L, const std::vector<std::pair<int
     h->L = L; h->Pk = next_pow2(L); h->PB = next_pow2(3 * L);
     h->RJ = round_up(L, SWEEP_TJ) + 4;
     h->pitchS = round_up(KOFF + L + 4, 16);
-    h->pitchT = round_up(L, 2);
-    if (const char* e = getenv("CETKMC_TPAD")) h->pitchT += 2 * atoi(e);   // experiment: row padding (doubles/2)
+    h->pitchT = round_up(L, 8);      // rows of the f64 fields are 64-B multiples: a sweep lane reads 8 entries unconditionally
     if (const char* e = getenv("CETKMC_IFC_BLOCK")) h->ifc_block = atoi(e);
     h->pitchC = round_up(KOFFC + L + 12, 16);
     h->shmem_stream = (size_t)STREAM_SLOTS * (SWEEP_TJ + 4) * h->pitchC;
@@ -577,10 +576,14 @@ int launch_sweep(Handle* h, bool batch, hipEvent_t ev_a = nullptr, hipEvent_t ev
             const StreamArgs sa = stream_args(h, v);
             const dim3 g(sa.group_count * njt);
             const bool tab = h->sweep_variant == 1, hw = h->Pk <= 256;
-            if (tab && hw) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_stream<true, true>), g, dim3(256), h->shmem_stream, h->stream, sa, ss);
-            else if (tab) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_stream<true, false>), g, dim3(256), h->shmem_stream, h->stream, sa, ss);
-            else if (hw) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_stream<false, true>), g, dim3(256), h->shmem_stream, h->stream, sa, ss);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_stream<false, false>), g, dim3(256), h->shmem_stream, h->stream, sa, ss);
+            const int npf = ((SWEEP_TJ + 4) * h->pitchC / 16 + 255) / 256;       // 16-B chunks of a class slab per thread
+#define CETKMC_LAUNCH_STREAM(TAB, HW, NPF) \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_stream<TAB, HW, NPF>), g, dim3(256), h->shmem_stream, h->stream, sa, ss)
+            if (hw) { if (tab) CETKMC_LAUNCH_STREAM(true, true, 1); else CETKMC_LAUNCH_STREAM(false, true, 1); }
+            else if (npf == 1) { if (tab) CETKMC_LAUNCH_STREAM(true, false, 1); else CETKMC_LAUNCH_STREAM(false, false, 1); }
+            else if (npf == 2) { if (tab) CETKMC_LAUNCH_STREAM(true, false, 2); else CETKMC_LAUNCH_STREAM(false, false, 2); }
+            else { if (tab) CETKMC_LAUNCH_STREAM(true, false, 3); else CETKMC_LAUNCH_STREAM(false, false, 3); }
+#undef CETKMC_LAUNCH_STREAM
         } else {
             hipLaunchKernelGGL(k_sweep_simple, dim3(v.nloc * njt), dim3(256), shmem0, h->stream, h->kp, v, h->d_ktab, ss);
         }

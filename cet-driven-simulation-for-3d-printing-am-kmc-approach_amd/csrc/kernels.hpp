@@ -316,12 +316,29 @@ __device__ __forceinline__ double tree8(const double (&x)[8])
     return ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
 }
 
+// The lane's 8 streamed values (rate-table entries, or temperatures for the recompute variant) of chunk m of row
+// jrow of local plane li: 64 contiguous bytes (rows are padded to a multiple of 8 doubles).  Issued one work item
+// ahead by the streaming kernel, so that the memory latency runs under the previous row's arithmetic.
+template <bool TAB, bool HW>
+__device__ __forceinline__ void load_vals(const StreamArgs& A, int li, int jrow, int lane, int m, double (&v)[8])
+{
+    // unconditional (straight-line code lets the compiler keep these loads in flight across the previous row's
+    // arithmetic): lanes outside the lattice read a clamped, valid address; their class bytes are zero, which masks
+    // whatever they load
+    const int k0 = min((m << 9) + 8 * (HW ? (lane & 31) : lane), A.pitchT - 8);
+    const int jr = min(jrow, A.L - 1);
+    const double2* src = reinterpret_cast<const double2*>((TAB ? A.vval : A.T) + ((int64_t)li * A.L + jr) * A.pitchT + k0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const double2 t = src[q]; v[2 * q] = t.x; v[2 * q + 1] = t.y; }
+}
+
 // One lattice row per wave (HW: per half-wave; `jrow` is then the lane's own row) of plane li: census + rates +
 // canonical row reduction, results to rowsum/rowcnt.  `rowp(d, dj)` returns the class-row pointer (at k = 0) of plane
 // li+d, row jrow+dj -- an LDS ring slot in the streaming kernel, the global class array in the dirty-row kernel;
-// everything else is shared, so both produce bit-identical row sums.
+// everything else is shared, so both produce bit-identical row sums.  v0 = load_vals() of chunk 0.
 template <bool TAB, bool HW, class ROWP>
-__device__ __forceinline__ void sweep_row(const StreamArgs& A, ROWP rowp, int li, int lp, int jrow, bool top, int lane)
+__device__ __forceinline__ void sweep_row(const StreamArgs& A, ROWP rowp, int li, int lp, int jrow, bool top, int lane,
+                                          const double (&v0)[8])
 {
     const int L = A.L;
     const int sl = HW ? (lane & 31) : lane;
@@ -337,13 +354,13 @@ __device__ __forceinline__ void sweep_row(const StreamArgs& A, ROWP rowp, int li
         const int64_t trow = ((int64_t)li * L + jrow) * A.pitchT + k0;
         double v[8], ev[8];
         uint2 own = make_uint2(0u, 0u), acc = make_uint2(0u, 0u);
+        if (m == 0) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = 0.0;
+            for (int q = 0; q < 8; ++q) v[q] = v0[q];
+        } else {
+            load_vals<TAB, HW>(A, li, jrow, lane, m, v);
+        }
         if (active) {
-            const double* src = (TAB ? A.vval : A.T) + trow;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (k0 + 2 * q < L) { const double2 t = *reinterpret_cast<const double2*>(src + 2 * q); v[2 * q] = t.x; v[2 * q + 1] = t.y; }
             // ---- census of the 8 voxels' 14 neighbours: OR of class bytes ---------------------------
             auto ld8 = [&](const uint8_t* p) { return *reinterpret_cast<const uint2*>(p + k0); };
             auto ld4 = [&](const uint8_t* p, int off) { return *reinterpret_cast<const unsigned*>(p + k0 + off); };
@@ -390,26 +407,31 @@ __device__ __forceinline__ void sweep_row(const StreamArgs& A, ROWP rowp, int li
                     ev[h] = nuc_bulk(A.T_melt, A.delta_T_c, A.kT, A.I0, A.rate_threshold, A.K0, v[h]);
             }
         }
-        // ---- interface voxels of the lane: event counts (and, recompute variant, their sums) ------------
-        const unsigned long long ibits = ((unsigned long long)(ifE.y | ifA.y) << 32) | (ifE.x | ifA.x);
-        const unsigned long long ebits = ((unsigned long long)ifE.y << 32) | ifE.x;
+        // ---- interface voxels of the lane: event counts from bits 7:2 of their own class byte (kept by ifc_store()),
+        // no memory access.  The ballots below count an empty voxel with a non-zero EMPTY-category sum once; an
+        // interface voxel's sum is non-zero iff it owns events (every kept rate is > rate_threshold): add count - 1.
+        const uint2 iany = make_uint2(ifE.x | ifA.x, ifE.y | ifA.y);
         double dv[8];
 #pragma unroll
         for (int h = 0; h < 8; ++h) dv[h] = 0.0;
         const bool diff_here = __any((ifA.x | ifA.y) != 0u);
-        if (__any(ibits != 0ull)) {
+        if (__any((iany.x | iany.y) != 0u)) {
             any_ifc = true;
-            unsigned long long bits = ibits;
-            while (bits) {
-                const int b = __builtin_ctzll(bits);
-                bits &= bits - 1;
-                const int h = b >> 3;
-                const int c = A.ifc_cnt[trow + h];
-                const bool isE = (ebits >> b) & 1ull;
-                // the ballots below count an empty voxel with a non-zero EMPTY-category sum once: an interface voxel's
-                // sum is non-zero iff it owns events (every kept rate is > rate_threshold)
-                cI += isE ? (c - (c > 0)) : (c << 16);
-                if (!TAB) {
+            const uint2 c6 = make_uint2((own.x >> 2) & 0x3F3F3F3Fu, (own.y >> 2) & 0x3F3F3F3Fu);
+            const uint2 cE = make_uint2(c6.x & (ifE.x * 255u), c6.y & (ifE.y * 255u));
+            const uint2 cA = make_uint2(c6.x & (ifA.x * 255u), c6.y & (ifA.y * 255u));
+            const unsigned nz = __popc(((cE.x + 0x3F3F3F3Fu) >> 6) & 0x01010101u) + __popc(((cE.y + 0x3F3F3F3Fu) >> 6) & 0x01010101u);
+            const unsigned nE = __builtin_amdgcn_sad_u8(cE.x, 0u, __builtin_amdgcn_sad_u8(cE.y, 0u, 0u)) - nz;
+            const unsigned nA = __builtin_amdgcn_sad_u8(cA.x, 0u, __builtin_amdgcn_sad_u8(cA.y, 0u, 0u));
+            cI += (int)(nE | (nA << 16));
+            if (!TAB) {         // recompute variant: the interface voxels' sums come from the table
+                unsigned long long bits = ((unsigned long long)iany.y << 32) | iany.x;
+                const unsigned long long ebits = ((unsigned long long)ifE.y << 32) | ifE.x;
+                while (bits) {
+                    const int b = __builtin_ctzll(bits);
+                    bits &= bits - 1;
+                    const int h = b >> 3;
+                    const bool isE = (ebits >> b) & 1ull;
                     const double x = A.vval[trow + h];
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
@@ -441,10 +463,9 @@ __device__ __forceinline__ void sweep_row(const StreamArgs& A, ROWP rowp, int li
 #pragma unroll
             for (int q = 0; q < 8; ++q) dp[q] = 0.0;
             if (active) {
-                const double* src = A.dep_val + (int64_t)jrow * A.pitchT + k0;
+                const double2* src = reinterpret_cast<const double2*>(A.dep_val + (int64_t)jrow * A.pitchT + k0);
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (k0 + 2 * q < L) { const double2 t = *reinterpret_cast<const double2*>(src + 2 * q); dp[2 * q] = t.x; dp[2 * q + 1] = t.y; }
+                for (int q = 0; q < 4; ++q) { const double2 t = src[q]; dp[2 * q] = t.x; dp[2 * q + 1] = t.y; }
             }
 #pragma unroll
             for (int h = 0; h < 8; ++h) {
@@ -473,7 +494,8 @@ __device__ __forceinline__ void sweep_row(const StreamArgs& A, ROWP rowp, int li
     }
 }
 
-template <bool TAB, bool HW>
+// NPF = 16-B chunks of a class slab per thread (1 for L <= 256, up to 3 for L <= 682)
+template <bool TAB, bool HW, int NPF>
 __global__ __launch_bounds__(256) CETKMC_SWEEP_ATTR void k_sweep_stream(StreamArgs A, const StepState* __restrict__ ss)
 {
     if (ss && ss->status) return;
@@ -490,44 +512,82 @@ __global__ __launch_bounds__(256) CETKMC_SWEEP_ATTR void k_sweep_stream(StreamAr
     const int lp0 = (A.group_first + ibr) * STREAM_NI, lp1 = min(lp0 + STREAM_NI, A.nloc);
     const int pitchC = A.pitchC;
     const int slab = TR * pitchC;                                     // bytes per plane slab
-    const int nchunk = slab >> 4;                                     // 16-B chunks per slab
-    // class slab of local plane lsrc (rows j0-2 .. j0+TJ+1) -> registers -> ring slot lsrc % STREAM_SLOTS
-    uint4 pf[STREAM_MAXPF];
+    const int nchunk = slab >> 4;                                     // 16-B chunks per slab (<= 256 * NPF)
+    const int64_t pstride = (int64_t)A.RJ * pitchC / 16;              // uint4 per class plane
+    const uint4* cls4 = reinterpret_cast<const uint4*>(A.cls + (int64_t)j0 * pitchC);
+    // class slab of local plane lsrc (rows j0-2 .. j0+TJ+1) -> registers -> ring slot lsrc % STREAM_SLOTS.  Unconditional,
+    // clamped loads: straight-line code, so the compiler can count what is in flight.
+    uint4 pf[NPF];
     auto fetch_slab = [&](int lsrc) {
-        const uint4* src = reinterpret_cast<const uint4*>(A.cls + ((int64_t)lsrc * A.RJ + j0) * pitchC);
+        const uint4* src = cls4 + min(lsrc, A.nloc + 3) * pstride;
 #pragma unroll
-        for (int q = 0; q < STREAM_MAXPF; ++q) { const int idx = tid + 256 * q; if (idx < nchunk) pf[q] = src[idx]; }
+        for (int q = 0; q < NPF; ++q) pf[q] = src[min(tid + 256 * q, nchunk - 1)];
     };
     auto store_slab = [&](int lsrc) {
         uint4* dst = reinterpret_cast<uint4*>(smem + (lsrc % STREAM_SLOTS) * slab);
 #pragma unroll
-        for (int q = 0; q < STREAM_MAXPF; ++q) { const int idx = tid + 256 * q; if (idx < nchunk) dst[idx] = pf[q]; }
+        for (int q = 0; q < NPF; ++q) if (tid + 256 * q < nchunk) dst[tid + 256 * q] = pf[q];
     };
-    for (int d = 0; d < 5; ++d) { fetch_slab(lp0 + d); store_slab(lp0 + d); }     // planes li-2 .. li+2 of the first plane
+    // work items: (plane, row pass); a wave's row of pass rr is j0 + r(rr).  The values of item n+1 and the class slab of
+    // the next plane are requested before item n is computed; two value buffers alternate (no register copies).
+    constexpr int NP = HW ? 1 : TJ / 4;
+    auto row_of = [&](int rr) { return HW ? (2 * w + (lane >> 5)) : (w + 4 * rr); };
+    double va[8], vb[8];
+    load_vals<TAB, HW>(A, lp0 + 2, j0 + row_of(0), lane, 0, va);
+    {   // planes li-2 .. li+2 of the first plane: all five slabs requested before the first is stored
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) {
+            const int idx = min(tid + 256 * q, nchunk - 1);
+            uint4 t[5];
+#pragma unroll
+            for (int d = 0; d < 5; ++d) t[d] = cls4[(lp0 + d) * pstride + idx];
+            if (tid + 256 * q < nchunk) {
+#pragma unroll
+                for (int d = 0; d < 5; ++d) reinterpret_cast<uint4*>(smem + ((lp0 + d) % STREAM_SLOTS) * slab)[idx] = t[d];
+            }
+        }
+    }
     __syncthreads();
-#pragma unroll 1
-    for (int lp = lp0; lp < lp1; ++lp) {
+    // one plane: its NP row passes; `cur` holds the first pass's values on entry, `nxt` the next plane's first pass on exit
+    auto plane = [&](int lp, double (&cur)[8], double (&nxt)[8]) {
         const int li = lp + 2;
         const bool top = (A.gi0 + lp == L - 1);
-        const bool more = lp + 1 < lp1;
-        if (more) fetch_slab(li + 3);                                // next plane's new slab: in flight during this plane
         int so[5];
 #pragma unroll
         for (int d = 0; d < 5; ++d) so[d] = ((li - 2 + d) % STREAM_SLOTS) * slab;
-        if (HW) {
-            const int r = 2 * w + (lane >> 5);
+        fetch_slab(li + 3);                  // next plane's new slab (a clamped dummy after the last plane): requested first,
+                                             // stored at the end of this plane while the value loads are still in flight
+        if (NP == 1) {
+            load_vals<TAB, HW>(A, min(li + 1, A.nloc + 1), j0 + row_of(0), lane, 0, nxt);
+            const int r = row_of(0);
             auto rowp = [&](int d, int dj) { return (const uint8_t*)smem + so[d + 2] + (r + 2 + dj) * pitchC + KOFFC; };
-            sweep_row<TAB, true>(A, rowp, li, lp, j0 + r, top, lane);
+            sweep_row<TAB, HW>(A, rowp, li, lp, j0 + r, top, lane, cur);
         } else {
-#pragma unroll 1
-            for (int rr = 0; rr < TJ / 4; ++rr) {
-                const int r = w + 4 * rr;
+            {
+                load_vals<TAB, HW>(A, li, j0 + row_of(1), lane, 0, nxt);
+                const int r = row_of(0);
                 auto rowp = [&](int d, int dj) { return (const uint8_t*)smem + so[d + 2] + (r + 2 + dj) * pitchC + KOFFC; };
-                sweep_row<TAB, false>(A, rowp, li, lp, j0 + r, top, lane);
+                sweep_row<TAB, HW>(A, rowp, li, lp, j0 + r, top, lane, cur);
+            }
+            {
+                load_vals<TAB, HW>(A, min(li + 1, A.nloc + 1), j0 + row_of(0), lane, 0, cur);
+                const int r = row_of(1);
+                auto rowp = [&](int d, int dj) { return (const uint8_t*)smem + so[d + 2] + (r + 2 + dj) * pitchC + KOFFC; };
+                sweep_row<TAB, HW>(A, rowp, li, lp, j0 + r, top, lane, nxt);
             }
         }
-        if (more) store_slab(li + 3);        // the sixth slot: not among the five this plane's stencil reads
+        store_slab(li + 3);                  // the sixth slot: not among the five this plane's stencil reads
         __syncthreads();
+    };
+    if (NP == 1) {
+#pragma unroll 1
+        for (int lp = lp0; lp < lp1; lp += 2) {
+            plane(lp, va, vb);
+            if (lp + 1 < lp1) plane(lp + 1, vb, va);
+        }
+    } else {
+#pragma unroll 1
+        for (int lp = lp0; lp < lp1; ++lp) plane(lp, va, vb);     // two passes: va -> vb -> va
     }
 }
 
@@ -554,7 +614,9 @@ __global__ __launch_bounds__(256) void k_rows_eval(StreamArgs A, const int* __re
         const int li = lp + 2;
         const int jrow = (HW && lane >= 32) ? L_INACTIVE : j;       // the second half-wave idles
         auto rowp = [&](int d, int dj) { return A.cls + ((int64_t)(li + d) * A.RJ + (j + 2 + dj)) * A.pitchC + KOFFC; };
-        sweep_row<TAB, HW>(A, rowp, li, lp, jrow, A.gi0 + lp == A.L - 1, lane);
+        double v0[8];
+        load_vals<TAB, HW>(A, li, jrow, lane, 0, v0);
+        sweep_row<TAB, HW>(A, rowp, li, lp, jrow, A.gi0 + lp == A.L - 1, lane, v0);
     }
     __syncthreads();
     // the block that finishes a plane's last dirty row reduces that plane's three category blocks (waves 0..2);
@@ -587,7 +649,7 @@ __global__ __launch_bounds__(256) void k_rate_table(KParams P, SlabView S, doubl
         const int64_t t = ((int64_t)2 * L + row) * S.pitchT + 2 * kp;       // local plane lp + 2
         const double2 Tv = *reinterpret_cast<const double2*>(S.T + t);
         double2 r;
-        r.x = nuc_bulk(P.T_melt, P.delta_T_c, P.kT, P.I0, P.rate_threshold, K0, Tv.x);
+        r.x = (2 * kp < L) ? nuc_bulk(P.T_melt, P.delta_T_c, P.kT, P.I0, P.rate_threshold, K0, Tv.x) : 0.0;      // row padding: 0
         r.y = (2 * kp + 1 < L) ? nuc_bulk(P.T_melt, P.delta_T_c, P.kT, P.I0, P.rate_threshold, K0, Tv.y) : 0.0;
         *reinterpret_cast<double2*>(S.vval + t) = r;
     }
@@ -971,6 +1033,16 @@ __device__ __forceinline__ void ifc_eval_atom(const KParams& P, const SlabView& 
     }
 }
 
+// result of a listed voxel's evaluation: table entry, event count, and the count mirrored into bits 7:2 of the voxel's
+// class byte (the sweep reads it there, from LDS, instead of gathering ifc_cnt); bits 1:0 (class8) are kept
+__device__ __forceinline__ void ifc_store(const SlabView& S, int li, int j, int k, int64_t t, double sum, int cnt)
+{
+    S.vval[t] = sum;
+    S.ifc_cnt[t] = (uint8_t)cnt;
+    uint8_t* c = S.cls + S.cidx(li, j, k);
+    *c = (uint8_t)((*c & 3u) | ((unsigned)cnt << 2));
+}
+
 // after an event changed voxel (i,j,k): it and its 14 neighbours may have become interface voxels,
 // and the category sums of those already listed are stale (their neighbour states / orientations
 // changed).  Called by a full wave: lane l < 15 handles one of the 15 voxels: append if needed, then
@@ -1002,8 +1074,7 @@ __device__ __forceinline__ void ifc_touch(const KParams& P, const SlabView& S, c
         int cnt = 0;
         if (st == 0) ifc_eval_empty(P, S, ktab, lp, aj, ak, t, code, Tc, sum, cnt);
         else if (st != 4) ifc_eval_atom(P, S, lp, aj, ak, t, code, st, Tc, sum, cnt);
-        S.vval[t] = sum;
-        S.ifc_cnt[t] = (uint8_t)cnt;
+        ifc_store(S, li, aj, ak, t, sum, cnt);
     }
 }
 // every step: EMPTY/DIFF category sum + count of every listed voxel, one voxel per lane.
@@ -1029,8 +1100,7 @@ __global__ __launch_bounds__(256) void k_interface(KParams P, SlabView S, const 
         int cnt = 0;
         if (st == 0) ifc_eval_empty(P, S, ktab, lp, j, k, t, code, Tc, sum, cnt);
         else if (st != 4) ifc_eval_atom(P, S, lp, j, k, t, code, st, Tc, sum, cnt);
-        S.vval[t] = sum;
-        S.ifc_cnt[t] = (uint8_t)cnt;
+        ifc_store(S, lp + 2, j, k, t, sum, cnt);
     }
 }
 
@@ -1060,7 +1130,7 @@ __global__ __launch_bounds__(256) void k_interface_part(KParams P, SlabView S, c
                 const unsigned code = S.ifc_code[S.tidx((int)(v >> 20) + 2, (v >> 10) & 1023, v & 1023)];
                 if (code >> 30) {                                       // no events: result is zero
                     const int64_t t = S.tidx((int)(v >> 20) + 2, (v >> 10) & 1023, v & 1023);
-                    S.vval[t] = 0.0; S.ifc_cnt[t] = 0;
+                    ifc_store(S, (int)(v >> 20) + 2, (v >> 10) & 1023, v & 1023, t, 0.0, 0);
                 } else if (((code >> 28) & 3u) == 0) qe[atomicAdd(&ne, 1)] = v;
                 else qa[atomicAdd(&na, 1)] = v;
             }
@@ -1079,8 +1149,7 @@ __global__ __launch_bounds__(256) void k_interface_part(KParams P, SlabView S, c
             int cnt = 0;
             if (is_e) ifc_eval_empty(P, S, ktab, lp, j, k, t, code, Tc, sum, cnt);
             else ifc_eval_atom(P, S, lp, j, k, t, code, (int)((code >> 28) & 3u), Tc, sum, cnt);
-            S.vval[t] = sum;
-            S.ifc_cnt[t] = (uint8_t)cnt;
+            ifc_store(S, lp + 2, j, k, t, sum, cnt);
         }
     }
 }

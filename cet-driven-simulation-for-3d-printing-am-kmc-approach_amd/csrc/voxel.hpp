@@ -58,7 +58,8 @@ struct SlabView {
     uint8_t* defects;   // same layout
     uint8_t* row_chg;   // [(nloc+4)][L]: 1 if a voxel of row (li, j) was written since prev_state was last brought level with
                         // state (the latent-heat test of the temperature update only looks at such rows)
-    uint8_t* cls;       // [(nloc+4)][RJ][pitchC] neighbour-census class of every voxel (class8())
+    uint8_t* cls;       // [(nloc+4)][RJ][pitchC] neighbour-census class of every voxel: bits 1:0 class8(), bits 7:2 the event
+                        // count of a listed (interface) voxel (ifc_store(); 0 until its first evaluation)
     double* T;          // [(nloc+4)][L][pitchT]  (current buffer)
     double* theta;
     double* phi;
