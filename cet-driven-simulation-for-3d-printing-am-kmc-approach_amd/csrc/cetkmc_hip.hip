@@ -534,11 +534,13 @@ int launch_dirty_rows(Handle* h, hipEvent_t ev_a, hipEvent_t ev_b)
         const int* dl = h->d_dirty;
         int* pc = h->d_dirty + 1 + DIRTY_MAX;
         const StepState* ss = h->d_ss;
-        const bool tab = h->sweep_variant == 1, hw = h->Pk <= 256;
-        if (tab && hw) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows_eval<true, true>), dim3(24), dim3(256), 0, h->stream, sa, dl, ss, h->d_blocks, pc);
-        else if (tab) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows_eval<true, false>), dim3(24), dim3(256), 0, h->stream, sa, dl, ss, h->d_blocks, pc);
-        else if (hw) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows_eval<false, true>), dim3(24), dim3(256), 0, h->stream, sa, dl, ss, h->d_blocks, pc);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows_eval<false, false>), dim3(24), dim3(256), 0, h->stream, sa, dl, ss, h->d_blocks, pc);
+        const bool tab = h->sweep_variant == 1, hw = h->Pk <= 256, ch2 = h->Pk > 512;
+#define CETKMC_LAUNCH_ROWS(TAB, HW, CH2) \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows_eval<TAB, HW, CH2>), dim3(24), dim3(256), 0, h->stream, sa, dl, ss, h->d_blocks, pc)
+        if (hw) { if (tab) CETKMC_LAUNCH_ROWS(true, true, false); else CETKMC_LAUNCH_ROWS(false, true, false); }
+        else if (!ch2) { if (tab) CETKMC_LAUNCH_ROWS(true, false, false); else CETKMC_LAUNCH_ROWS(false, false, false); }
+        else { if (tab) CETKMC_LAUNCH_ROWS(true, false, true); else CETKMC_LAUNCH_ROWS(false, false, true); }
+#undef CETKMC_LAUNCH_ROWS
     }
     if (ev_b) HIPCHK(hipEventRecord(ev_b, h->stream));
     HIPCHK(hipGetLastError());
@@ -577,12 +579,14 @@ int launch_sweep(Handle* h, bool batch, hipEvent_t ev_a = nullptr, hipEvent_t ev
             const dim3 g(sa.group_count * njt);
             const bool tab = h->sweep_variant == 1, hw = h->Pk <= 256;
             const int npf = ((SWEEP_TJ + 4) * h->pitchC / 16 + 255) / 256;       // 16-B chunks of a class slab per thread
-#define CETKMC_LAUNCH_STREAM(TAB, HW, NPF) \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_stream<TAB, HW, NPF>), g, dim3(256), h->shmem_stream, h->stream, sa, ss)
-            if (hw) { if (tab) CETKMC_LAUNCH_STREAM(true, true, 1); else CETKMC_LAUNCH_STREAM(false, true, 1); }
-            else if (npf == 1) { if (tab) CETKMC_LAUNCH_STREAM(true, false, 1); else CETKMC_LAUNCH_STREAM(false, false, 1); }
-            else if (npf == 2) { if (tab) CETKMC_LAUNCH_STREAM(true, false, 2); else CETKMC_LAUNCH_STREAM(false, false, 2); }
-            else { if (tab) CETKMC_LAUNCH_STREAM(true, false, 3); else CETKMC_LAUNCH_STREAM(false, false, 3); }
+#define CETKMC_LAUNCH_STREAM(TAB, HW, NPF, CH2) \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_stream<TAB, HW, NPF, CH2>), g, dim3(256), h->shmem_stream, h->stream, sa, ss)
+            const bool ch2 = h->Pk > 512;       // L > 512: pitchC >= 544, so npf >= 2
+            if (hw) { if (tab) CETKMC_LAUNCH_STREAM(true, true, 1, false); else CETKMC_LAUNCH_STREAM(false, true, 1, false); }
+            else if (npf == 1) { if (tab) CETKMC_LAUNCH_STREAM(true, false, 1, false); else CETKMC_LAUNCH_STREAM(false, false, 1, false); }
+            else if (npf == 2 && !ch2) { if (tab) CETKMC_LAUNCH_STREAM(true, false, 2, false); else CETKMC_LAUNCH_STREAM(false, false, 2, false); }
+            else if (npf == 2) { if (tab) CETKMC_LAUNCH_STREAM(true, false, 2, true); else CETKMC_LAUNCH_STREAM(false, false, 2, true); }
+            else { if (tab) CETKMC_LAUNCH_STREAM(true, false, 3, true); else CETKMC_LAUNCH_STREAM(false, false, 3, true); }
 #undef CETKMC_LAUNCH_STREAM
         } else {
             hipLaunchKernelGGL(k_sweep_simple, dim3(v.nloc * njt), dim3(256), shmem0, h->stream, h->kp, v, h->d_ktab, ss);

@@ -336,18 +336,20 @@ __device__ __forceinline__ void load_vals(const StreamArgs& A, int li, int jrow,
 // canonical row reduction, results to rowsum/rowcnt.  `rowp(d, dj)` returns the class-row pointer (at k = 0) of plane
 // li+d, row jrow+dj -- an LDS ring slot in the streaming kernel, the global class array in the dirty-row kernel;
 // everything else is shared, so both produce bit-identical row sums.  v0 = load_vals() of chunk 0.
-template <bool TAB, bool HW, class ROWP>
+// CH2: rows of 513..1024 voxels (two 512-voxel chunks per row; only without HW).
+template <bool TAB, bool HW, bool CH2, class ROWP>
 __device__ __forceinline__ void sweep_row(const StreamArgs& A, ROWP rowp, int li, int lp, int jrow, bool top, int lane,
                                           const double (&v0)[8])
 {
+    static_assert(!(HW && CH2), "half-wave rows have one chunk");
     const int L = A.L;
     const int sl = HW ? (lane & 31) : lane;
-    const int nch = HW ? 1 : (A.Pk >> 9);                    // chunks of 512 voxels (Pk >= 512 unless HW)
+    constexpr int nch = CH2 ? 2 : 1;                         // chunks of 512 voxels
     double r0 = 0.0, r1 = 0.0, r2 = 0.0;                     // row totals (chunk tree: nch <= 2)
     int nE_a = 0, nE_b = 0, nD_a = 0, nD_b = 0;              // scalar event counts: whole wave / half a, half b
     int cI = 0;                                              // lane: interface counts, EMPTY | DIFF << 16
     bool any_ifc = false;
-#pragma unroll 1
+#pragma unroll
     for (int m = 0; m < nch; ++m) {
         const int k0 = (m << 9) + 8 * sl;
         const bool active = jrow < L && k0 < L;
@@ -495,7 +497,7 @@ __device__ __forceinline__ void sweep_row(const StreamArgs& A, ROWP rowp, int li
 }
 
 // NPF = 16-B chunks of a class slab per thread (1 for L <= 256, up to 3 for L <= 682)
-template <bool TAB, bool HW, int NPF>
+template <bool TAB, bool HW, int NPF, bool CH2>
 __global__ __launch_bounds__(256) CETKMC_SWEEP_ATTR void k_sweep_stream(StreamArgs A, const StepState* __restrict__ ss)
 {
     if (ss && ss->status) return;
@@ -561,19 +563,19 @@ __global__ __launch_bounds__(256) CETKMC_SWEEP_ATTR void k_sweep_stream(StreamAr
             load_vals<TAB, HW>(A, min(li + 1, A.nloc + 1), j0 + row_of(0), lane, 0, nxt);
             const int r = row_of(0);
             auto rowp = [&](int d, int dj) { return (const uint8_t*)smem + so[d + 2] + (r + 2 + dj) * pitchC + KOFFC; };
-            sweep_row<TAB, HW>(A, rowp, li, lp, j0 + r, top, lane, cur);
+            sweep_row<TAB, HW, CH2>(A, rowp, li, lp, j0 + r, top, lane, cur);
         } else {
             {
                 load_vals<TAB, HW>(A, li, j0 + row_of(1), lane, 0, nxt);
                 const int r = row_of(0);
                 auto rowp = [&](int d, int dj) { return (const uint8_t*)smem + so[d + 2] + (r + 2 + dj) * pitchC + KOFFC; };
-                sweep_row<TAB, HW>(A, rowp, li, lp, j0 + r, top, lane, cur);
+                sweep_row<TAB, HW, CH2>(A, rowp, li, lp, j0 + r, top, lane, cur);
             }
             {
                 load_vals<TAB, HW>(A, min(li + 1, A.nloc + 1), j0 + row_of(0), lane, 0, cur);
                 const int r = row_of(1);
                 auto rowp = [&](int d, int dj) { return (const uint8_t*)smem + so[d + 2] + (r + 2 + dj) * pitchC + KOFFC; };
-                sweep_row<TAB, HW>(A, rowp, li, lp, j0 + r, top, lane, nxt);
+                sweep_row<TAB, HW, CH2>(A, rowp, li, lp, j0 + r, top, lane, nxt);
             }
         }
         store_slab(li + 3);                  // the sixth slot: not among the five this plane's stencil reads
@@ -597,7 +599,7 @@ __global__ __launch_bounds__(256) CETKMC_SWEEP_ATTR void k_sweep_stream(StreamAr
 // memory -- with the same sweep_row() as the streaming kernel, so every row sum equals what a full sweep
 // would have produced.  dirty[0] = count, dirty[1..] = (global plane << 16) | row.
 constexpr int DIRTY_MAX = 63;
-template <bool TAB, bool HW>
+template <bool TAB, bool HW, bool CH2>
 __global__ __launch_bounds__(256) void k_rows_eval(StreamArgs A, const int* __restrict__ dirty,
                                                    const StepState* __restrict__ ss, BlockEnt* __restrict__ blocks, int* plane_cnt)
 {
@@ -616,7 +618,7 @@ __global__ __launch_bounds__(256) void k_rows_eval(StreamArgs A, const int* __re
         auto rowp = [&](int d, int dj) { return A.cls + ((int64_t)(li + d) * A.RJ + (j + 2 + dj)) * A.pitchC + KOFFC; };
         double v0[8];
         load_vals<TAB, HW>(A, li, jrow, lane, 0, v0);
-        sweep_row<TAB, HW>(A, rowp, li, lp, jrow, A.gi0 + lp == A.L - 1, lane, v0);
+        sweep_row<TAB, HW, CH2>(A, rowp, li, lp, jrow, A.gi0 + lp == A.L - 1, lane, v0);
     }
     __syncthreads();
     // the block that finishes a plane's last dirty row reduces that plane's three category blocks (waves 0..2);
@@ -818,23 +820,32 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
     }
     __syncthreads();
     const int j = sh_j;
-    // voxels of row (i, c, j): re-evaluate.  Interface voxels are all listed (invariant of the
-    // interface list) and k_interface has left their full EMPTY/DIFF category sum in vval.
+    // voxels of row (i, c, j).  With the rate table (ifc_ready): a leaf is a lookup -- listed voxels hold their full
+    // EMPTY/DIFF category sum and count (k_interface / ifc_touch; every interface voxel is listed), every other empty
+    // voxel its nucleation rate by temperature (k_rate_table), plane L-1 its deposition rates (dep_val).  Without it
+    // (simple kernel): re-evaluated here.
     for (int k = tid; k < Pk; k += 256) {
         double sum = 0.0; int cnt = 0;
         int maybe_ifc = 1;      // 0: certainly no interface voxel (its EMPTY category can only hold a nucleation)
         if (k < L) {
-            // state, membership flag, stored interface sum and temperature are requested together (one round trip)
+            // state, membership flag, table entry, count (and temperature) are requested together (one round trip)
             const int64_t t = S.tidx(li, j, k);
             const int st = S.state[S.sidx(li, j, k)];
             const bool listed = ifc_ready && S.ifc_in[t] != 0;
             maybe_ifc = (!ifc_ready || listed) ? 1 : 0;
-            const double v_ifc = S.vval[t];
+            const double v_tab = S.vval[t];
             const int c_ifc = S.ifc_cnt[t];
-            const double Traw = S.T[t];
-            if (c != CAT_DEP && listed) {
-                if ((c == CAT_EMPTY) == (st == 0)) { sum = v_ifc; cnt = c_ifc; }
+            if (ifc_ready) {
+                if (c == CAT_DEP) {
+                    const double rate = S.dep_val[(int64_t)j * S.pitchT + k];
+                    if (st == 0 && finite_d(rate)) { sum = rate; cnt = 1; }
+                } else if (listed) {
+                    if ((c == CAT_EMPTY) == (st == 0)) { sum = v_tab; cnt = c_ifc; }
+                } else if (c == CAT_EMPTY && st == 0) {
+                    sum = v_tab; cnt = (v_tab != 0.0) ? 1 : 0;
+                }
             } else {
+                const double Traw = S.T[t];
                 auto nb = [&](int mm) -> int { return S.state[S.sidx(li + nbi_rt(mm), j + nbj_rt(mm), k + nbk_rt(mm))]; };
                 auto emit = [&](int cat, int, double rate, int, int) { if (cat == c) { sum += rate; ++cnt; } };
                 eval_voxel(P, S, ktab, li, i, j, k, st, Traw, nb, emit);
@@ -960,6 +971,7 @@ __global__ void k_ifc_rebuild(SlabView S)
 }
 // EMPTY-category sum of a listed empty voxel (nuc + attachments) / DIFF-category sum of a listed atom, from its
 // packed neighbourhood word alone
+template <int BATCH = 4>
 __device__ __forceinline__ void ifc_eval_empty(const KParams& P, const SlabView& S, const double* ktab, int lp, int j, int k,
                                                int64_t t, unsigned code, double Tc, double& sum, int& cnt)
 {
@@ -983,11 +995,11 @@ __device__ __forceinline__ void ifc_eval_empty(const KParams& P, const SlabView&
     }
     if (mask) {
         const AttCtx c = att_ctx(P, S, li, j, k, Tc);
-        while (mask) {                                   // batches of 4 attachment sources
-            int ms[4];
-            double b[4][3];
+        while (mask) {                                   // batches of BATCH attachment sources: one memory round trip each
+            int ms[BATCH];
+            double b[BATCH][3];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < BATCH; ++u) {
                 ms[u] = mask ? __builtin_ctz(mask) : -1;
                 mask &= mask - 1;
                 const int m = ms[u] < 0 ? 0 : ms[u];
@@ -995,7 +1007,7 @@ __device__ __forceinline__ void ifc_eval_empty(const KParams& P, const SlabView&
                 b[u][0] = p[0]; b[u][1] = p[1]; b[u][2] = p[2];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < BATCH; ++u) {
                 if (ms[u] >= 0) {
                     const int sn = (int)((code >> (2 * ms[u])) & 3u);
                     const double rate = att_item(P, c, b[u][0], b[u][1], b[u][2], sn);
@@ -1072,7 +1084,7 @@ __device__ __forceinline__ void ifc_touch(const KParams& P, const SlabView& S, c
         const double Tc = pymax(Traw, 1.0);
         double sum = 0.0;
         int cnt = 0;
-        if (st == 0) ifc_eval_empty(P, S, ktab, lp, aj, ak, t, code, Tc, sum, cnt);
+        if (st == 0) ifc_eval_empty<8>(P, S, ktab, lp, aj, ak, t, code, Tc, sum, cnt);     // one wave: registers are free
         else if (st != 4) ifc_eval_atom(P, S, lp, aj, ak, t, code, st, Tc, sum, cnt);
         ifc_store(S, li, aj, ak, t, sum, cnt);
     }

@@ -4,8 +4,9 @@
    (per-kernel average duration + HBM traffic from the FETCH_SIZE / WRITE_SIZE PMC passes).
 HBM traffic per launch = 2*FETCH_SIZE + WRITE_SIZE (KB -> bytes): on gfx950 FETCH_SIZE reports half
 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section); the x2 is applied to the
-streaming kernels (k_sweep_stream, k_thermal: 16-B-per-lane loads) and NOT to the narrow-gather
-kernels, whose calibration is unknown (reported raw, flagged)."""
+streaming kernels (k_sweep_stream, k_rate_table, k_thermal: 16-B-per-lane loads) and NOT to the narrow-gather
+kernels, whose calibration is unknown (reported raw, flagged).  FETCH_SIZE counts the L2's memory-side requests:
+Infinity-Cache hits are included, so it is fabric traffic, an upper bound of what reaches HBM."""
 import collections
 import csv
 import glob
@@ -22,10 +23,13 @@ os.makedirs(dst, exist_ok=True)
 
 
 def kname(raw):
-    """cetkmc::k_sweep_stream<8, true>(...) -> k_sweep_stream_wv (write-back instantiation, Mode B only)"""
+    """cetkmc::k_sweep_stream<true, true, 1, false>(...) -> k_sweep_stream (rate-table variant, any row shape);
+    <false, ...> -> k_sweep_stream_recompute; other templates: base name"""
     head = raw.split("(")[0].replace("cetkmc::", "").replace("void ", "")
     base = head.split("<")[0]
-    return base + ("_wv" if "<" in head and "true" in head.split("<", 1)[1] else "")
+    if base == "k_sweep_stream" and "<" in head and head.split("<", 1)[1].strip().startswith("false"):
+        return "k_sweep_stream_recompute"
+    return base
 
 
 def one(pattern):
@@ -54,7 +58,7 @@ for which in ("fetch", "write"):
         summary["kernels"].setdefault(name, {})[f"{which}_size_kb_median"] = statistics.median(v)
 for name, k in summary["kernels"].items():
     if "fetch_size_kb_median" in k and "write_size_kb_median" in k:
-        wide = name in ("k_sweep_stream", "k_thermal", "k_thermal_march")
+        wide = name in ("k_sweep_stream", "k_sweep_stream_recompute", "k_rate_table", "k_thermal", "k_thermal_march")
         k["hbm_bytes_per_launch"] = (2.0 if wide else 1.0) * k["fetch_size_kb_median"] * 1024 + k["write_size_kb_median"] * 1024
         k["fetch_x2_applied"] = wide
 modes = one(f"{tag}_stats_modes/*/*kernel_stats.csv")
