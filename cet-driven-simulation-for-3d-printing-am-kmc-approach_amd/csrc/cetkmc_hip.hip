@@ -617,14 +617,14 @@ int launch_select(Handle* h, const BatchCfg& cfg, double r_direct, int info_only
 
 // selection + application of one batched step: one fused launch in a single process, select / all-gather / apply
 // across ranks
-int launch_select_apply(Handle* h, const BatchCfg& cfg, int eval_touched, int* dirty)
+int launch_select_apply(Handle* h, const BatchCfg& cfg, int eval_touched, int* dirty, int64_t cur_hint)
 {
     if (!multi_rank(h)) {
         hipLaunchKernelGGL(k_select_apply, dim3(1), dim3(256), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
                            (int)h->slabs.size(), h->L, h->PB, (const BlockEnt*)h->d_blocks, h->d_ss, cfg,
                            (const double*)h->d_u_pick, (const double*)h->d_ktab, h->d_events_all + h->my_first,
                            h->sweep_variant >= 1 ? 1 : 0, (const double*)h->d_u_defect, (const double*)h->d_u_np,
-                           h->d_log_total, h->d_log_event, h->d_log_nev, eval_touched, dirty);
+                           h->d_log_total, h->d_log_event, h->d_log_nev, eval_touched, dirty, (long long)cur_hint);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -1184,11 +1184,11 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
                 HIPCHK(hipEventRecord(pev(s, 2), h->stream));
                 CHK(launch_dirty_rows(h, nullptr, pev(s, 3)));
                 HIPCHK(hipEventRecord(pev(s, 4), h->stream));
-                CHK(launch_select_apply(h, cfg, 1, h->d_dirty));
+                CHK(launch_select_apply(h, cfg, 1, h->d_dirty, s));
                 HIPCHK(hipEventRecord(pev(s, 5), h->stream));
             } else {
                 CHK(launch_dirty_rows(h, sampled(s) ? h->prof[2 * s] : nullptr, sampled(s) ? h->prof[2 * s + 1] : nullptr));
-                CHK(launch_select_apply(h, cfg, 1, h->d_dirty));
+                CHK(launch_select_apply(h, cfg, 1, h->d_dirty, s));
             }
             h->swept = false;
             continue;
@@ -1203,7 +1203,7 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
         if (a->profile == 2) CHK(launch_sweep(h, true, pev(s, 2), pev(s, 3), false, pev(s, 1), pev(s, 4)));
         else if (sampled(s)) CHK(launch_sweep(h, true, h->prof[2 * s], h->prof[2 * s + 1]));
         else CHK(launch_sweep(h, true));
-        CHK(launch_select_apply(h, cfg, (incr || eval_touched) ? 1 : 0, incr ? h->d_dirty : nullptr));
+        CHK(launch_select_apply(h, cfg, (incr || eval_touched) ? 1 : 0, incr ? h->d_dirty : nullptr, s));
         if (!(incr || eval_touched)) h->ifc_fresh = false;
         if (a->profile == 2) HIPCHK(hipEventRecord(pev(s, 5), h->stream));
         h->swept = false;
@@ -1553,6 +1553,15 @@ int cetkmc_reset_counters(void* handle)
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }
+
+#ifdef CETKMC_SEL_STAMPS
+int cetkmc_debug_sel_stamps(long long out[16])      /* alternative builds only (tools/sel_stamps.py); not part of the ABI */
+{
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(cetkmc::g_sel_stamps), 16 * sizeof(long long)));
+    return 0;
+}
+#endif
 
 int cetkmc_time_sweeps(void* handle, int n, double* ms_total)
 {

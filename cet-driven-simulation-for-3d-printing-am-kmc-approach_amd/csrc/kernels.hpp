@@ -726,12 +726,32 @@ __device__ __forceinline__ int heap_descend(const double* hs, const int* hf, int
     return n - P;
 }
 
+// A/B instrumentation (tools/sel_stamps.py, alternative build with -DCETKMC_SEL_STAMPS): thread 0 records the 100 MHz
+// wall clock at the phase boundaries of the fused selection + application kernel
+#ifdef CETKMC_SEL_STAMPS
+__device__ long long g_sel_stamps[16];
+#define SEL_STAMP(q) do { if (threadIdx.x == 0) g_sel_stamps[q] = wall_clock64(); } while (0)
+#else
+#define SEL_STAMP(q) do { } while (0)
+#endif
+
+// What the selection already holds when the application starts (fused launch: same block, thread 0): the step state
+// and the step's uniforms, requested behind the selection's own loads instead of in a chain of their own.
+struct SelCarry {
+    double total, u_def, u_th, u_ph;
+    long long n_events, n_dep, np_pos, cur;
+    int ready;
+};
+
 // k_select: single block.  (1) total + termination checks, (2) block descent, (3) row descent
-// in the owning slab, (4) voxel descent with the row's rates re-evaluated, (5) slot scan.
+// in the owning slab, (4) voxel descent (leaves looked up in the rate table), (5) slot scan.
+// cur_hint >= 0: the batch step index as the host knows it (== ss->cur while status == 0): saves a dependent load.
 __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __restrict__ slabs, int nslabs, int L,
                                             int PB, const BlockEnt* __restrict__ blocks, StepState* ss,
                                             const BatchCfg& cfg, const double* __restrict__ u_pick, double r_direct,
-                                            const double* __restrict__ ktab_g, cetkmc_event* my_event, int info_only, int ifc_ready)
+                                            const double* __restrict__ ktab_g, cetkmc_event* my_event, int info_only, int ifc_ready,
+                                            long long cur_hint = -1, SelCarry* carry = nullptr,
+                                            const double* __restrict__ u_defect = nullptr, const double* __restrict__ u_np = nullptr)
 {
     __shared__ double hs[2 * PMAX];
     __shared__ int hf[2 * PMAX];
@@ -741,19 +761,34 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
     __shared__ double sh_base, sh_r;
     __shared__ int sh_go, sh_b, sh_slab, sh_j, sh_k;
     __shared__ int sh_gi0[64], sh_nloc[64];
+    __shared__ long long sh_ndep;
     const int tid = threadIdx.x;
-    if (cfg.batch && ss->status) return;
-    // everything thread 0 will need after the first heap is requested now, behind the block loads: the step's uniform,
-    // the stream cursor and the slabs' plane ranges
-    double u0 = 0.0;
-    long long np_pos0 = 0;
-    if (tid == 0 && cfg.batch) { u0 = u_pick[ss->cur]; np_pos0 = ss->np_pos; }
+    SEL_STAMP(0);
+    // everything thread 0 will need after the first heap is requested now, behind the block loads: the batch status, the
+    // step's uniforms, the stream cursor and the slabs' plane ranges; the first slab's view (the only one in most runs)
+    // comes with them
+    double u0 = 0.0, u_def = 0.0, u_th = 0.0, u_ph = 0.0;
+    long long np_pos0 = 0, cur = 0;
+    int status0 = 0;
+    if (tid == 0 && cfg.batch) {
+        status0 = ss->status;
+        np_pos0 = ss->np_pos;
+        cur = cur_hint >= 0 ? cur_hint : ss->cur;
+        u0 = u_pick[cur];
+        if (carry && u_defect && cfg.defect_fraction > 0.0) u_def = u_defect[cur];
+        if (carry && u_np && cfg.rng_mode == 1 && np_pos0 + 2 <= cfg.np_cap) { u_th = u_np[np_pos0]; u_ph = u_np[np_pos0 + 1]; }
+    }
+    if (tid == 0 && carry) carry->ready = 0;
+    const SlabView S0 = slabs[0];
     if (tid < nslabs && tid < 64) { sh_gi0[tid] = slabs[tid].gi0; sh_nloc[tid] = slabs[tid].nloc; }
     const int NBk = 3 * L;
     long long csum = 0;
     for (int idx = tid; idx < PB; idx += 256) {
         double v = 0.0; int f = 0;
-        if (idx < NBk) { v = blocks[idx].sum; long long c = blocks[idx].cnt; f = c > 0; csum += c; }
+        if (idx < NBk) {
+            v = blocks[idx].sum; long long c = blocks[idx].cnt; f = c > 0; csum += c;
+            if (idx == 3 * (L - 1) + CAT_DEP) sh_ndep = c;
+        }
         hs[PB + idx] = v; hf[PB + idx] = f;
     }
     if (tid < 225) ktab[tid] = ktab_g[tid];
@@ -761,11 +796,14 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
     for (int l = 0; l < 6; ++l) csum += __shfl_xor(csum, 1 << l);       // per-wave event count
     if ((tid & 63) == 0) red[tid >> 6] = csum;
     __syncthreads();
+    SEL_STAMP(1);
     heap_build(hs, hf, PB, tid);
-    if (tid == 0) {
+    SEL_STAMP(2);
+    if (tid == 0 && status0) sh_go = 0;                 // terminated / exhausted batch: nothing is read or written
+    else if (tid == 0) {
         const double total = hs[1];
         const long long n_events = red[0] + red[1] + red[2] + red[3];
-        const long long n_dep = blocks[3 * (L - 1) + CAT_DEP].cnt;
+        const long long n_dep = sh_ndep;
         ss->total = total; ss->n_events = n_events; ss->n_dep = n_dep;
         int go = info_only ? 0 : 1;
         if (!info_only) my_event->type = -1;
@@ -792,12 +830,20 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
             }
             sh_b = b; sh_slab = sl; sh_base = base; sh_r = r;
             if (sl < 0) go = 0;     // owned by another rank
+            if (go && carry) {
+                // reference stream: the orientation draws follow this sweep's n_dep species draws
+                if (u_np && cfg.rng_mode == 0) { u_th = u_np[np_pos0 + n_dep]; u_ph = u_np[np_pos0 + n_dep + 1]; }
+                carry->total = total; carry->n_events = n_events; carry->n_dep = n_dep; carry->np_pos = np_pos0; carry->cur = cur;
+                carry->u_def = u_def; carry->u_th = u_th; carry->u_ph = u_ph;
+                carry->ready = 1;
+            }
         }
         sh_go = go;
     }
     __syncthreads();
+    SEL_STAMP(3);
     if (!sh_go) return;
-    const SlabView S = slabs[sh_slab];
+    const SlabView S = (sh_slab == 0) ? S0 : slabs[sh_slab];
     const int b = sh_b, i = b / 3, c = b - 3 * i;
     const int lp = i - S.gi0, li = lp + 2;
     const double r = sh_r;
@@ -809,6 +855,7 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
         hs[Pk + idx] = v; hf[Pk + idx] = cv > 0; leafcnt[idx] = cv;
     }
     __syncthreads();
+    SEL_STAMP(4);
     heap_build(hs, hf, Pk, tid);
     if (tid == 0) {
         double base = sh_base;
@@ -819,6 +866,7 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
         sh_j = j; sh_base = base;
     }
     __syncthreads();
+    SEL_STAMP(5);
     const int j = sh_j;
     // voxels of row (i, c, j).  With the rate table (ifc_ready): a leaf is a lookup -- listed voxels hold their full
     // EMPTY/DIFF category sum and count (k_interface / ifc_touch; every interface voxel is listed), every other empty
@@ -854,7 +902,9 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
         hs[Pk + k] = sum; hf[Pk + k] = cnt > 0; leafcnt[k] = cnt | (maybe_ifc << 8);
     }
     __syncthreads();
+    SEL_STAMP(6);
     heap_build(hs, hf, Pk, tid);
+    SEL_STAMP(7);
     if (tid == 0) {
         double base = sh_base;
         const int k = heap_descend(hs, hf, Pk, base, r);
@@ -899,6 +949,7 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
         }
         *my_event = ev;
     }
+    SEL_STAMP(8);
 }
 
 __global__ __launch_bounds__(256) void k_select(KParams P, const SlabView* __restrict__ slabs, int nslabs, int L,
@@ -1060,8 +1111,11 @@ __device__ __forceinline__ void ifc_store(const SlabView& S, int li, int j, int 
 // changed).  Called by a full wave: lane l < 15 handles one of the 15 voxels: append if needed, then
 // re-evaluate if listed -- this keeps vval/ifc_cnt exact when k_interface ran BEFORE the event
 // (the speculative, overlapped launch of the batched loop).
+// dedupe: the wave touches TWO neighbourhoods (a diffusion: site and target), so two lanes may hold the same voxel and
+// the list append needs the atomic test-and-set; otherwise the <= 15 voxels are distinct and the appends of the wave
+// share one atomic.
 __device__ __forceinline__ void ifc_touch(const KParams& P, const SlabView& S, const double* ktab, int i, int j, int k, int lane,
-                                          int eval)
+                                          int eval, bool dedupe)
 {
     if (lane >= 15) return;
     int ai = i, aj = j, ak = k;
@@ -1077,7 +1131,23 @@ __device__ __forceinline__ void ifc_touch(const KParams& P, const SlabView& S, c
     const double Traw = eval ? S.T[t] : 0.0;
     bool hit;
     const unsigned code = ifc_encode(S, li, aj, ak, &hit);
-    if (hit && !listed) { ifc_append(S, lp, aj, ak); listed = true; }
+    if (dedupe) {
+        if (hit && !listed) { ifc_append(S, lp, aj, ak); listed = true; }
+    } else {
+        const bool want = hit && !listed;
+        const unsigned long long m = __ballot(want);                 // the lanes still here (same slab, inside the lattice)
+        if (m) {
+            const int leader = __builtin_ctzll(m);
+            int base = 0;
+            if (lane == leader) base = atomicAdd(S.ifc_n, __popcll(m));
+            base = __shfl(base, leader);
+            if (want) {
+                S.ifc_in[t] = 1;
+                S.ifc_list[base + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned)lp << 20) | ((unsigned)aj << 10) | (unsigned)ak;
+                listed = true;
+            }
+        }
+    }
     if (listed) S.ifc_code[t] = code;
     if (eval && listed) {            // the same evaluation from the packed word as k_interface
         const int st = (code >> 30) ? 4 : (int)((code >> 28) & 3u);
@@ -1202,8 +1272,9 @@ __device__ __forceinline__ void apply_touch(const KParams& P, const SlabView* sl
     for (int s = 0; s < nslabs; ++s) {
         const SlabView& S = slabs[s];
         // lanes 0..14: neighbourhood of the event site; lanes 16..30: neighbourhood of a diffusion target
-        if (lane < 16) ifc_touch(P, S, ktab, ev.pos[0], ev.pos[1], ev.pos[2], lane, eval);
-        else if (ev.type == EV_DIFF) ifc_touch(P, S, ktab, ev.target[0], ev.target[1], ev.target[2], lane - 16, eval);
+        const bool two = ev.type == EV_DIFF;
+        if (lane < 16) ifc_touch(P, S, ktab, ev.pos[0], ev.pos[1], ev.pos[2], lane, eval, two);
+        else if (two) ifc_touch(P, S, ktab, ev.target[0], ev.target[1], ev.target[2], lane - 16, eval, two);
     }
 }
 
@@ -1235,48 +1306,55 @@ __device__ __forceinline__ void apply_batch_body(const KParams& P, const SlabVie
                                                  const BatchCfg& cfg, const double* __restrict__ u_defect,
                                                  const double* __restrict__ u_np, double* log_total,
                                                  cetkmc_event* log_event, int64_t* log_nev,
-                                                 const double* __restrict__ ktab_g, int eval_touched, int* dirty)
+                                                 const double* __restrict__ ktab_g, int eval_touched, int* dirty,
+                                                 const SelCarry* carry = nullptr)
 {
     __shared__ cetkmc_event sh_ev;
     __shared__ int sh_ok;
+    SEL_STAMP(9);
     if (threadIdx.x == 0) {
         sh_ok = 0;
-        if (!ss->status) {
+        const bool have = carry && carry->ready;            // fused launch: the selection succeeded in this block
+        if (have || (!carry && !ss->status)) {
             cetkmc_event ev;
             ev.type = -1;
             for (int g = 0; g < G; ++g) if (events_all[g].type >= 0) ev = events_all[g];
-            const int64_t s = ss->cur;
+            const int64_t s = have ? carry->cur : ss->cur;
             if (ev.type < 0) {
                 ss->status = 1;
             } else {
-                int64_t pos = ss->np_pos;
+                int64_t pos = have ? carry->np_pos : ss->np_pos;
+                const int64_t n_dep = have ? carry->n_dep : ss->n_dep;
                 if (ev.type == EV_DEP) {
                     const double u = (cfg.rng_mode == 0)
                         ? u_np[pos + ev.dep_rank]
                         : counter_uniform(cfg.seed, (uint64_t)(cfg.step0 + s), (uint64_t)ev.pos[1] * (uint64_t)L + (uint64_t)ev.pos[2]);
                     ev.atom = dep_species(P, u);
                 }
-                if (cfg.rng_mode == 0) pos += ss->n_dep;
+                if (cfg.rng_mode == 0) pos += n_dep;
                 if (ev.type == EV_DEP || ev.type == EV_NUC) {
-                    ev.theta = 0.0 + (3.141592653589793 - 0.0) * u_np[pos];       // np.random.uniform(0, pi)
-                    ev.phi = 0.0 + (6.283185307179586 - 0.0) * u_np[pos + 1];     // np.random.uniform(0, 2*pi)
+                    const double ut = have ? carry->u_th : u_np[pos], up = have ? carry->u_ph : u_np[pos + 1];
+                    ev.theta = 0.0 + (3.141592653589793 - 0.0) * ut;       // np.random.uniform(0, pi)
+                    ev.phi = 0.0 + (6.283185307179586 - 0.0) * up;         // np.random.uniform(0, 2*pi)
                     pos += 2;
                     if (ev.type == EV_NUC) ss->nuc_count += 1;
                 }
-                const int mk = (cfg.defect_fraction > 0.0 && u_defect[s] < cfg.defect_fraction) ? 1 : 0;
+                const int mk = (cfg.defect_fraction > 0.0 && (have ? carry->u_def : u_defect[s]) < cfg.defect_fraction) ? 1 : 0;
                 apply_event(slabs, nslabs, ev, mk);
                 ss->np_pos = pos;
-                if (log_total) log_total[s] = ss->total;
+                if (log_total) log_total[s] = have ? carry->total : ss->total;
                 if (log_event) log_event[s] = ev;
-                if (log_nev) log_nev[s] = ss->n_events;
+                if (log_nev) log_nev[s] = have ? carry->n_events : ss->n_events;
                 ss->cur = s + 1;
                 sh_ev = ev;
                 sh_ok = 1;
             }
         }
     }
+    SEL_STAMP(10);
     __syncthreads();
     if (sh_ok) apply_touch(P, slabs, nslabs, ktab_g, sh_ev, threadIdx.x, eval_touched);
+    SEL_STAMP(11);
     if (dirty && threadIdx.x == 0) {
         // rows whose rates may have changed: the rows of the changed voxel(s) and of their 14 neighbours
         int n = 0;
@@ -1316,16 +1394,17 @@ __global__ __launch_bounds__(256) void k_select_apply(KParams P, const SlabView*
                                                       const double* __restrict__ ktab_g, cetkmc_event* my_event, int ifc_ready,
                                                       const double* __restrict__ u_defect, const double* __restrict__ u_np,
                                                       double* log_total, cetkmc_event* log_event, int64_t* log_nev,
-                                                      int eval_touched, int* dirty)
+                                                      int eval_touched, int* dirty, long long cur_hint)
 {
-    __shared__ cetkmc_event sh_sel;            // the chosen event goes from the selection to the application through LDS
+    __shared__ cetkmc_event sh_sel;            // the chosen event goes from the selection to the application through LDS,
+    __shared__ SelCarry sh_carry;              // and so do the step state and the uniforms the selection requested early
     (void)my_event;
     if (threadIdx.x == 0) sh_sel.type = -1;
     __syncthreads();
-    select_body(P, slabs, nslabs, L, PB, blocks, ss, cfg, u_pick, 0.0, ktab_g, &sh_sel, 0, ifc_ready);
+    select_body(P, slabs, nslabs, L, PB, blocks, ss, cfg, u_pick, 0.0, ktab_g, &sh_sel, 0, ifc_ready, cur_hint, &sh_carry, u_defect, u_np);
     __syncthreads();
     apply_batch_body(P, slabs, nslabs, L, &sh_sel, 1, ss, cfg, u_defect, u_np, log_total, log_event, log_nev, ktab_g,
-                     eval_touched, dirty);
+                     eval_touched, dirty, &sh_carry);
 }
 
 // Direct apply (cetkmc_apply): everything decided by the host.  ONE 64-thread block.

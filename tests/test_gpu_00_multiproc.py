@@ -156,3 +156,57 @@ def test_mode_b_ranks_sharing_one_gpu_match_single_process(world, L, box, therma
         i0, i1 = int(z["i0"]), int(z["i1"])
         for k in ("state", "theta", "phi", "T", "defects"):
             assert np.array_equal(z[k], ref[k][i0:i1]), k
+
+
+# ---- the same with the RCCL communicator, one GPU per rank: collected everywhere, runs where >= 2 GPUs are visible ----
+def _worker_rccl(rank, world, port, L, n, seed, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    root = os.path.dirname(HERE)
+    sys.path.insert(0, os.path.join(root, "cet-driven-simulation-for-3d-printing-am-kmc-approach_amd"))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cetkmc
+    box = [cetkmc.Engine.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    fields, streams = _inputs(L, n, seed)
+    eng = cetkmc.Engine(L, impurity_c=0.2, device=rank, rank=rank, nranks=world, unique_id=box[0])
+    a0, a1 = max(0, eng.i0 - 2), min(L, eng.i1 + 2)
+    r, d, info = _run(eng, a0, a1, fields, streams, n, "full")
+    rb = eng.run_supersteps(n, 16, 8, 0.05, seed=9, thermal_mode=1, want_events=True)
+    db = eng.download_planes(eng.i0, eng.i1, state=True, theta=True)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), totals=r["totals"], events=r["events"], i0=eng.i0, i1=eng.i1,
+             b_events=rb["events"], b_state=db["state"], b_theta=db["theta"], **d)
+    eng.close()
+    dist.barrier()
+    if rank == 0:
+        ref = cetkmc.Engine(L, impurity_c=0.2, device=0)
+        r, d, info = _run(ref, 0, L, fields, streams, n, "full")
+        rb = ref.run_supersteps(n, 16, 8, 0.05, seed=9, thermal_mode=1, want_events=True)
+        db = ref.download_planes(0, L, state=True, theta=True)
+        np.savez(os.path.join(out_dir, "ref.npz"), totals=r["totals"], events=r["events"], b_events=rb["events"],
+                 b_state=db["state"], b_theta=db["theta"], **d)
+        ref.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_over_rccl_match_single_process(tmp_path):
+    """Mode A batch + Mode B super-steps with a real 2-rank RCCL communicator (one GPU per rank: ncclAllGather of the
+    block sums / event records, ncclSend/ncclRecv of the temperature halo and of the boundary box layers' events):
+    bit-identical to the single-process engine.  The build box and the round's test box have ONE GPU: skipped there
+    (N > 1 over RCCL has not been executed by the builder; the same per-rank code runs above over the host relay)."""
+    import cetkmc
+    if cetkmc.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    import torch.multiprocessing as mp
+    world, L, n = 2, 32, 40
+    mp.spawn(_worker_rccl, args=(world, _free_port(), L, n, 31, str(tmp_path)), nprocs=world, join=True)
+    ref = np.load(tmp_path / "ref.npz")
+    zs = [np.load(tmp_path / f"rank{rank}.npz") for rank in range(world)]
+    assert np.concatenate([z["b_events"] for z in zs], axis=1).tobytes() == ref["b_events"].tobytes()
+    for z in zs:
+        assert np.array_equal(z["totals"], ref["totals"]) and z["events"].tobytes() == ref["events"].tobytes()
+        i0, i1 = int(z["i0"]), int(z["i1"])
+        for k in ("state", "theta", "phi", "T", "defects"):
+            assert np.array_equal(z[k], ref[k][i0:i1]), k
+        assert np.array_equal(z["b_state"], ref["b_state"][i0:i1]) and np.array_equal(z["b_theta"], ref["b_theta"][i0:i1])

@@ -649,3 +649,94 @@ def test_incremental_256_vs_oracle(oracle_mod):
         assert np.array_equal(rg["events"][f], ro["events"][f]), f
     assert np.array_equal(rg["n_events"], ro["n_events"])
     assert relerr(rg["totals"], ro["totals"]).max() <= RATE_RTOL
+
+
+def test_terminating_step_consumes_its_species_draws(oracle_mod):
+    """kmc_event_rates.py:65 draws one NumPy uniform per finite-rate deposition candidate BEFORE run_kmc tests the total
+    (kmc_simulation.py:259-262): a run that terminates with candidates left has consumed them.  run_kmc itself cannot
+    get there (an empty site at T >= T_SUB always owns a large nucleation rate), so no reference fixture covers this
+    step -- parity unpinned; device and oracle are compared with each other.  Here: I0 = 0 (no nucleation), cold
+    lattice (every deposition rate underflows to 0.0, which is finite and therefore a candidate), total = 0."""
+    import cetkmc
+    L = 8
+    state = np.zeros((L, L, L), np.int64)
+    state[:, :, 0] = 4                                  # a defect layer: no events of its own
+    zeros = np.zeros((L, L, L))
+    T = np.full((L, L, L), 1000.0)
+    params = cetkmc.default_params(0.2)
+    params.I0 = 0.0
+    e = cetkmc.Engine(L, impurity_c=0.2, params=params)
+    e.upload(state, zeros, zeros, T, np.zeros((L, L, L), np.int64))
+    lat = oracle_mod.Lattice(state, zeros, zeros, T, None, impurity_c=0.2)
+    lat.params.I0 = 0.0
+    n_top = L * (L - 1)                                 # empty sites of plane L-1
+    assert e.rate_sweep() == (0.0, n_top, n_top)
+    rs = np.random.RandomState(0)
+    n = 3
+    u_pick, u_np = rs.random_sample(n), rs.random_sample(n * (L * L + 2))
+    rg = e.run_steps(0, n, 0.0, u_pick, None, u_np, rng_mode=0, thermal_mode=0)
+    ro = lat.run_steps(0, n, 0.0, u_pick, None, u_np, rng_mode=0, thermal_mode=0)
+    assert rg["done"] == ro["done"] == 0 and rg["status"] == ro["status"] == 1
+    assert rg["np_used"] == ro["np_used"] == n_top
+    # the stream is too short for the terminating step's draws: status 2 (refill), nothing consumed
+    rg = e.run_steps(0, n, 0.0, u_pick, None, u_np[:n_top - 1], rng_mode=0, thermal_mode=0)
+    ro = lat.run_steps(0, n, 0.0, u_pick, None, u_np[:n_top - 1], rng_mode=0, thermal_mode=0)
+    assert rg["status"] == ro["status"] == 2 and rg["np_used"] == ro["np_used"] == 0
+    # counter mode draws nothing from the stream
+    rg = e.run_steps(0, n, 0.0, u_pick, None, u_np, rng_mode=1, seed=3, thermal_mode=0)
+    assert rg["status"] == 1 and rg["np_used"] == 0
+    e.close()
+
+
+def test_config5_workload_at_size(oracle_mod):
+    """BASELINE config 5's workload at its full size on ONE GPU: 512^3, eight in-process axis-0 slabs (the 8-GPU
+    decomposition), impurity_c = 0.2, laser thermal mode, counter RNG.  (a) the first steps equal the oracle's (16
+    threads): chosen events, counts, totals <= 1e-11; (b) the defect refresh without moving the lattice
+    (defects.py:4-19 on the carbon sites) gives the mask the host path gives; (c) the same steps with ONE slab are
+    bit-identical, and that engine clusters the lattice (utils.py:28-84) with every occupied voxel labelled."""
+    import cetkmc
+    import defects as defects_mod
+    from cetkmc import synthetic
+    from oracle import oracle
+    L, n = 512, 3
+    st, th, ph, T, df = synthetic.planes(L, 0, L, seed=42)
+    rs = np.random.RandomState(4)
+    u_pick, u_def, u_np = rs.random_sample(n), rs.random_sample(n), rs.random_sample(2 * n + 2)
+    q = synthetic.laser_planes(L, 0, n)
+    outs = []
+    for ns in (8, 1):
+        e = cetkmc.Engine(L, impurity_c=0.2, n_slabs=ns)
+        e.upload_planes(0, L, st, th, ph, T, df)
+        e.set_prev_state(None)
+        info = e.rate_sweep()
+        r = e.run_steps(0, n, 3e-3, u_pick, u_def, u_np, rng_mode=1, seed=42, thermal_mode=2, q_planes=q)
+        assert r["done"] == n and r["status"] == 0
+        np.random.seed(7)
+        n_flag, _ = defects_mod.refresh_defects_device(e)
+        outs.append((info, r["totals"].tobytes(), r["events"].tobytes(), r["n_events"].tobytes(), n_flag, e.rate_sweep()))
+        if ns == 1:
+            cl = e.clusters(labels=True)
+            occ = e.download_planes(0, L, state=True)["state"] != 0
+            assert np.array_equal(cl["labels"] > 0, occ) and cl["size"].sum() == occ.sum()
+            del cl, occ
+        if ns == 8:
+            keep = (r, e.download_planes(0, L, defects=True)["defects"].copy())
+        e.close()
+    assert outs[0] == outs[1]
+    rg, mask_dev = keep
+    # oracle on the same steps
+    oracle.set_threads(16)
+    try:
+        lat = oracle.Lattice(st, th, ph, T, df, impurity_c=0.2)
+        ro = lat.run_steps(0, n, 3e-3, u_pick, u_def, u_np, rng_mode=1, seed=42, thermal_mode=2, q_planes=q)
+    finally:
+        oracle.set_threads(1)
+    assert ro["done"] == n
+    for f in ("type", "pos", "target", "atom"):
+        assert np.array_equal(rg["events"][f], ro["events"][f]), f
+    assert np.array_equal(rg["n_events"], ro["n_events"])
+    assert relerr(rg["totals"], ro["totals"]).max() <= RATE_RTOL
+    # host path of the defect refresh on the oracle's lattice (same stream position)
+    np.random.seed(7)
+    mask_host = defects_mod.track_defects(lat.state.astype(np.int64), lat.state.astype(np.int64), L, lat.T)
+    assert np.array_equal(mask_dev != 0, mask_host != 0)
