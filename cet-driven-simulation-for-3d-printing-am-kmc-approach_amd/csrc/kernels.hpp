@@ -1097,13 +1097,14 @@ __device__ __forceinline__ void ifc_eval_atom(const KParams& P, const SlabView& 
 }
 
 // result of a listed voxel's evaluation: table entry, event count, and the count mirrored into bits 7:2 of the voxel's
-// class byte (the sweep reads it there, from LDS, instead of gathering ifc_cnt); bits 1:0 (class8) are kept
-__device__ __forceinline__ void ifc_store(const SlabView& S, int li, int j, int k, int64_t t, double sum, int cnt)
+// class byte (the sweep reads it there, from LDS, instead of gathering ifc_cnt); bits 1:0 = class8(state), which the
+// packed neighbourhood word carries (write_site keeps cls and state level), so the byte is written without being read
+__device__ __forceinline__ int code_state(unsigned code) { return (code >> 30) ? 4 : (int)((code >> 28) & 3u); }
+__device__ __forceinline__ void ifc_store(const SlabView& S, int li, int j, int k, int64_t t, double sum, int cnt, unsigned code)
 {
     S.vval[t] = sum;
     S.ifc_cnt[t] = (uint8_t)cnt;
-    uint8_t* c = S.cls + S.cidx(li, j, k);
-    *c = (uint8_t)((*c & 3u) | ((unsigned)cnt << 2));
+    S.cls[S.cidx(li, j, k)] = (uint8_t)(class8(code_state(code)) | ((unsigned)cnt << 2));
 }
 
 // after an event changed voxel (i,j,k): it and its 14 neighbours may have become interface voxels,
@@ -1113,9 +1114,12 @@ __device__ __forceinline__ void ifc_store(const SlabView& S, int li, int j, int 
 // (the speculative, overlapped launch of the batched loop).
 // dedupe: the wave touches TWO neighbourhoods (a diffusion: site and target), so two lanes may hold the same voxel and
 // the list append needs the atomic test-and-set; otherwise the <= 15 voxels are distinct and the appends of the wave
-// share one atomic.
+// share one atomic, whose result is only consumed after the evaluation.
+// defer_centre (single neighbourhood only): the centre voxel (lane 14), if it is an atom, is NOT evaluated here:
+// centre_atom_eval() spreads its <= 14 diffusion items over the lanes of a wave (another wave of the block, where
+// there is one, so that it runs beside this function instead of after it).
 __device__ __forceinline__ void ifc_touch(const KParams& P, const SlabView& S, const double* ktab, int i, int j, int k, int lane,
-                                          int eval, bool dedupe)
+                                          int eval, bool dedupe, bool defer_centre)
 {
     if (lane >= 15) return;
     int ai = i, aj = j, ak = k;
@@ -1131,32 +1135,35 @@ __device__ __forceinline__ void ifc_touch(const KParams& P, const SlabView& S, c
     const double Traw = eval ? S.T[t] : 0.0;
     bool hit;
     const unsigned code = ifc_encode(S, li, aj, ak, &hit);
+    bool want = false;
+    unsigned long long m = 0ull;
+    int base = 0, leader = 0;
     if (dedupe) {
         if (hit && !listed) { ifc_append(S, lp, aj, ak); listed = true; }
     } else {
-        const bool want = hit && !listed;
-        const unsigned long long m = __ballot(want);                 // the lanes still here (same slab, inside the lattice)
+        want = hit && !listed;
+        m = __ballot(want);                                          // the lanes still here (same slab, inside the lattice)
         if (m) {
-            const int leader = __builtin_ctzll(m);
-            int base = 0;
-            if (lane == leader) base = atomicAdd(S.ifc_n, __popcll(m));
-            base = __shfl(base, leader);
-            if (want) {
-                S.ifc_in[t] = 1;
-                S.ifc_list[base + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned)lp << 20) | ((unsigned)aj << 10) | (unsigned)ak;
-                listed = true;
-            }
+            leader = __builtin_ctzll(m);
+            if (lane == leader) base = atomicAdd(S.ifc_n, __popcll(m));      // consumed at the end of the function
+            if (want) { S.ifc_in[t] = 1; listed = true; }
         }
     }
     if (listed) S.ifc_code[t] = code;
     if (eval && listed) {            // the same evaluation from the packed word as k_interface
-        const int st = (code >> 30) ? 4 : (int)((code >> 28) & 3u);
+        const int st = code_state(code);
         const double Tc = pymax(Traw, 1.0);
-        double sum = 0.0;
-        int cnt = 0;
-        if (st == 0) ifc_eval_empty<8>(P, S, ktab, lp, aj, ak, t, code, Tc, sum, cnt);     // one wave: registers are free
-        else if (st != 4) ifc_eval_atom(P, S, lp, aj, ak, t, code, st, Tc, sum, cnt);
-        ifc_store(S, li, aj, ak, t, sum, cnt);
+        if (!(defer_centre && lane == 14 && st >= 1 && st <= 3)) {
+            double sum = 0.0;
+            int cnt = 0;
+            if (st == 0) ifc_eval_empty<8>(P, S, ktab, lp, aj, ak, t, code, Tc, sum, cnt);     // one wave: registers are free
+            else if (st != 4) ifc_eval_atom(P, S, lp, aj, ak, t, code, st, Tc, sum, cnt);
+            ifc_store(S, li, aj, ak, t, sum, cnt, code);
+        }
+    }
+    if (m) {
+        base = __shfl(base, leader);
+        if (want) S.ifc_list[base + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned)lp << 20) | ((unsigned)aj << 10) | (unsigned)ak;
     }
 }
 // every step: EMPTY/DIFF category sum + count of every listed voxel, one voxel per lane.
@@ -1182,7 +1189,7 @@ __global__ __launch_bounds__(256) void k_interface(KParams P, SlabView S, const 
         int cnt = 0;
         if (st == 0) ifc_eval_empty(P, S, ktab, lp, j, k, t, code, Tc, sum, cnt);
         else if (st != 4) ifc_eval_atom(P, S, lp, j, k, t, code, st, Tc, sum, cnt);
-        ifc_store(S, lp + 2, j, k, t, sum, cnt);
+        ifc_store(S, lp + 2, j, k, t, sum, cnt, code);
     }
 }
 
@@ -1212,7 +1219,7 @@ __global__ __launch_bounds__(256) void k_interface_part(KParams P, SlabView S, c
                 const unsigned code = S.ifc_code[S.tidx((int)(v >> 20) + 2, (v >> 10) & 1023, v & 1023)];
                 if (code >> 30) {                                       // no events: result is zero
                     const int64_t t = S.tidx((int)(v >> 20) + 2, (v >> 10) & 1023, v & 1023);
-                    ifc_store(S, (int)(v >> 20) + 2, (v >> 10) & 1023, v & 1023, t, 0.0, 0);
+                    ifc_store(S, (int)(v >> 20) + 2, (v >> 10) & 1023, v & 1023, t, 0.0, 0, code);
                 } else if (((code >> 28) & 3u) == 0) qe[atomicAdd(&ne, 1)] = v;
                 else qa[atomicAdd(&na, 1)] = v;
             }
@@ -1231,7 +1238,7 @@ __global__ __launch_bounds__(256) void k_interface_part(KParams P, SlabView S, c
             int cnt = 0;
             if (is_e) ifc_eval_empty(P, S, ktab, lp, j, k, t, code, Tc, sum, cnt);
             else ifc_eval_atom(P, S, lp, j, k, t, code, (int)((code >> 28) & 3u), Tc, sum, cnt);
-            ifc_store(S, lp + 2, j, k, t, sum, cnt);
+            ifc_store(S, lp + 2, j, k, t, sum, cnt, code);
         }
     }
 }
@@ -1266,15 +1273,70 @@ __device__ __forceinline__ void apply_event(const SlabView* slabs, int nslabs, c
 }
 
 // interface-list update for the voxels an event touched (all lanes of the first wave)
-__device__ __forceinline__ void apply_touch(const KParams& P, const SlabView* slabs, int nslabs, const double* ktab,
-                                            const cetkmc_event& ev, int lane, int eval)
+// kmc_event_rates.py:93-107 for the atom an event has just placed at (i,j,k) -- the common case of every dep / nuc /
+// att event: its diffusion items one per lane (lane m = neighbour slot m), summed by lane 0 in slot order exactly like
+// ifc_eval_atom() does serially.  Called by all 64 lanes of ONE wave; every lane derives the (identical) packed word,
+// membership and context itself -- the same cache lines for all of them.  Counterpart of ifc_touch(defer_centre).
+__device__ __forceinline__ void centre_atom_eval(const KParams& P, const SlabView& S, int i, int j, int k, int lane)
 {
+    const int L = S.L;
+    const int lp = i - S.gi0;
+    if (i < 0 || i >= L || j < 0 || j >= L || k < 0 || k >= L || lp < 0 || lp >= S.nloc) return;
+    const int li = lp + 2;
+    const int64_t t = S.tidx(li, j, k);
+    const bool listed0 = S.ifc_in[t] != 0;
+    const double Tc = pymax(S.T[t], 1.0);
+    bool hit;
+    const unsigned code = ifc_encode(S, li, j, k, &hit);
+    const int st = code_state(code);
+    if (!(listed0 || hit) || st < 1 || st > 3) return;               // not listed, or evaluated by ifc_touch
+    int n_bonds = 0;
+    unsigned mask = 0;
+#pragma unroll
+    for (int m = 0; m < 14; ++m) {
+        const unsigned c = (code >> (2 * m)) & 3u;
+        n_bonds += (c == 2u);
+        if (c == 1u) mask |= 1u << m;
+    }
+    double rate = 0.0;
+    int ok = 0;
+    if (mask) {
+        const bool mine_item = lane < 14 && ((mask >> lane) & 1u);
+        const int m = lane < 14 ? lane : 0;
+        const double Tn = S.T[mine_item ? S.tidx(li + nbi_rt(m), j + nbj_rt(m), k + nbk_rt(m)) : t];
+        const DiffCtx c = diff_ctx(P, S, li, j, k, st, n_bonds, Tc);
+        if (mine_item) {
+            rate = diff_item(P, c, Tn);
+            ok = (rate > P.rate_threshold && finite_d(rate)) ? 1 : 0;
+        }
+    }
+    double sum = 0.0;
+    int cnt = 0;
+#pragma unroll
+    for (int m = 0; m < 14; ++m) {
+        const double r = __shfl(rate, m);
+        const int o = __shfl(ok, m);
+        if (o) { sum = sum + r; ++cnt; }
+    }
+    if (lane == 0) ifc_store(S, li, j, k, t, sum, cnt, code);
+}
+// tid / nthreads: the calling block's thread index and size (whole waves).  Wave 0: lanes 0..14 the neighbourhood of the
+// event site, lanes 16..30 the neighbourhood of a diffusion target; the atom a dep / nuc / att event placed is
+// evaluated by wave 1 (wave 0 in a one-wave block).
+__device__ __forceinline__ void apply_touch(const KParams& P, const SlabView* slabs, int nslabs, const double* ktab,
+                                            const cetkmc_event& ev, int tid, int eval, int nthreads)
+{
+    const int wave = tid >> 6, lane = tid & 63;
+    const bool two = ev.type == EV_DIFF;
+    const bool defer = !two && eval;
+    const int cw = nthreads >= 128 ? 1 : 0;
     for (int s = 0; s < nslabs; ++s) {
         const SlabView& S = slabs[s];
-        // lanes 0..14: neighbourhood of the event site; lanes 16..30: neighbourhood of a diffusion target
-        const bool two = ev.type == EV_DIFF;
-        if (lane < 16) ifc_touch(P, S, ktab, ev.pos[0], ev.pos[1], ev.pos[2], lane, eval, two);
-        else if (two) ifc_touch(P, S, ktab, ev.target[0], ev.target[1], ev.target[2], lane - 16, eval, two);
+        if (wave == 0) {
+            if (lane < 16) ifc_touch(P, S, ktab, ev.pos[0], ev.pos[1], ev.pos[2], lane, eval, two, defer);
+            else if (two) ifc_touch(P, S, ktab, ev.target[0], ev.target[1], ev.target[2], lane - 16, eval, two, false);
+        }
+        if (defer && wave == cw) centre_atom_eval(P, S, ev.pos[0], ev.pos[1], ev.pos[2], lane);
     }
 }
 
@@ -1353,7 +1415,7 @@ __device__ __forceinline__ void apply_batch_body(const KParams& P, const SlabVie
     }
     SEL_STAMP(10);
     __syncthreads();
-    if (sh_ok) apply_touch(P, slabs, nslabs, ktab_g, sh_ev, threadIdx.x, eval_touched);
+    if (sh_ok) apply_touch(P, slabs, nslabs, ktab_g, sh_ev, threadIdx.x, eval_touched, blockDim.x);
     SEL_STAMP(11);
     if (dirty && threadIdx.x == 0) {
         // rows whose rates may have changed: the rows of the changed voxel(s) and of their 14 neighbours
@@ -1416,7 +1478,7 @@ __global__ __launch_bounds__(64) void k_apply_direct(KParams P, const SlabView* 
         apply_event(slabs, nslabs, ev, make_defect);
     }
     __syncthreads();
-    apply_touch(P, slabs, nslabs, ktab_g, ev, threadIdx.x, 0);
+    apply_touch(P, slabs, nslabs, ktab_g, ev, threadIdx.x, 0, blockDim.x);
 }
 
 // ---- thermal -------------------------------------------------------------------------------
