@@ -1326,9 +1326,10 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
     HIPCHK(hipMalloc((void**)&d_dom, (size_t)NE * sizeof(cetkmc_event)));
     HIPCHK(hipMemsetAsync(d_dom, 0xFF, (size_t)NE * sizeof(cetkmc_event), h->stream));      // type -1: nothing received
     HIPCHK(hipMalloc((void**)&d_picks, (size_t)D * sizeof(DomPick)));
-    HIPCHK(hipMalloc((void**)&d_cnt, 2 * sizeof(unsigned long long)));
+    const size_t cnt_bytes = (size_t)SUPER_CNT_SLOTS * SUPER_CNT_STRIDE * sizeof(unsigned long long);
+    HIPCHK(hipMalloc((void**)&d_cnt, cnt_bytes));
     if (events && n > 0) HIPCHK(hipMalloc((void**)&d_log, (size_t)n * D * sizeof(cetkmc_event)));
-    HIPCHK(hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), h->stream));
+    HIPCHK(hipMemsetAsync(d_cnt, 0, cnt_bytes, h->stream));
     if (a->thermal_mode == 2 && n_therm > 0)
         HIPCHK(hipMemcpyAsync(h->d_q, a->q_planes, (size_t)n_therm * L2 * 8, hipMemcpyHostToDevice, h->stream));
     StepState ss;
@@ -1356,9 +1357,9 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
         CHK(launch_sweep(h, true, nullptr, nullptr, true));
         CHK(launch_select(h, cfg, 0.0, 1));                              // total, counts, termination test
         hipLaunchKernelGGL(k_domain_pick, dim3(D), dim3(64), shmem, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
-                           (int)h->slabs.size(), h->L, C, (const StepState*)h->d_ss, d_picks);
-        hipLaunchKernelGGL(k_domain_slot_apply, dim3((D + 63) / 64), dim3(64), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
-                           (int)h->slabs.size(), h->L, D, C, h->d_ss, (const DomPick*)d_picks, (const double*)h->d_ktab, d_dom, d_cnt, d_log);
+                           (int)h->slabs.size(), h->L, C, (const StepState*)h->d_ss, (const double*)h->d_ktab, d_picks);
+        hipLaunchKernelGGL(k_domain_apply, dim3((D + 63) / 64), dim3(64), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
+                           (int)h->slabs.size(), h->L, D, C, h->d_ss, (const DomPick*)d_picks, d_dom, d_cnt, d_log);
         int n_touch = D;
         if (ranks) {
             // the events of my bottom / top box layer go to the ranks below / above, theirs come here: every rank applies
@@ -1370,7 +1371,7 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
         }
         hipLaunchKernelGGL(k_domain_touch, dim3((n_touch + 7) / 8), dim3(256), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
                            (int)h->slabs.size(), n_touch, (const cetkmc_event*)d_dom, (const StepState*)h->d_ss, (const double*)h->d_ktab);
-        hipLaunchKernelGGL(k_super_commit, dim3(1), dim3(1), 0, h->stream, h->d_ss, d_cnt, h->d_log_total, h->d_log_nev);
+        hipLaunchKernelGGL(k_super_commit, dim3(1), dim3(64), 0, h->stream, h->d_ss, d_cnt, h->d_log_total, h->d_log_nev);
         h->swept = false;
     }
     if (n > 0) CHK(relist(h));        // leave a complete, address-ordered interface list behind (Mode A reads it)

@@ -12,6 +12,8 @@ namespace cetkmc {
 
 constexpr uint64_t KEY_PICK = 1ull << 40, KEY_THETA = 2ull << 40, KEY_PHI = 3ull << 40, KEY_DEFECT = 4ull << 40;
 
+constexpr int SUPER_CNT_SLOTS = 256, SUPER_CNT_STRIDE = 16;     // per-slot {executed, nucleations} counters, 128 B apart
+
 struct SuperCfg {
     int64_t step0;
     double defect_fraction;
@@ -21,36 +23,103 @@ struct SuperCfg {
     int32_t d0, D_loc;          // this handle's boxes: global indices [d0, d0 + D_loc) (box layers of its owned planes)
 };
 
-struct DomPick {          // result of the tree descent of one box
-    int32_t i, j, k, cat;  // cat < 0: idle box
-    double base, r;
-    double rate;           // simple: the chosen leaf itself (its single event's rate)
-    int32_t simple, pad;   // 1: a single event whose kind is known without evaluating the voxel again (deposition, or the
-                           // nucleation of an empty voxel that is not an interface voxel)
+// The slot scan of kmc_simulation.py:268-274 inside ONE chosen voxel by a whole wave: lane m < 14 evaluates the rate of
+// neighbour slot m (attachment from a W/Re/C neighbour, or diffusion into an empty one), lane 14 the nucleation; lane 0
+// then walks them in the reference's order (nucleation, then slots 0..13) with the running sum starting at `base`.
+// Same arithmetic as eval_voxel() (att_ctx/att_item, diff_ctx/diff_item, nuc_rate with the K_eff table).  Result
+// (lane 0): type, slot, species, rate of the first event with cum >= r, else of the last valid one.
+struct SlotPick { int type, m, atom; double rate; };
+__device__ __forceinline__ SlotPick slot_scan_wave(const KParams& P, const SlabView& S, const double* ktab, int li, int j, int k,
+                                                   int c, double base, double r, int lane)
+{
+    const int64_t t = S.tidx(li, j, k);
+    const int st = S.state[S.sidx(li, j, k)];
+    const double Tc = pymax(S.T[t], 1.0);
+    const int m = lane < 14 ? lane : 0;
+    const int di = nbi_rt(m), dj = nbj_rt(m), dk = nbk_rt(m);
+    const int sm = lane < 14 ? (int)S.state[S.sidx(li + di, j + dj, k + dk)] : (int)OOB;
+    const unsigned long long M14 = 0x3FFFull;
+    const int n_nb = __popcll(__ballot(sm != OOB) & M14);
+    const int n_imp = __popcll(__ballot(sm == 2 || sm == 3) & M14);
+    const int n_bonds = __popcll(__ballot(sm != 0 && sm != OOB) & M14);
+    double rate = 0.0;
+    int ok = 0, atom = 0;
+    if (c == CAT_EMPTY && st == 0) {
+        if (lane == 14) {
+            const double dT = P.T_melt - Tc;
+            if (dT > P.delta_T_c) {
+                rate = nuc_rate(P, ktab[n_nb * 15 + n_imp], dT, P.kT * Tc);
+                ok = (rate > P.rate_threshold && finite_d(rate)) ? 1 : 0;
+                atom = 1;
+            }
+        } else if (lane < 14 && sm >= 1 && sm <= 3) {
+            const AttCtx cx = att_ctx(P, S, li, j, k, Tc);
+            const double* b = S.ovec + 3 * S.tidx(li + di, j + dj, k + dk);
+            rate = att_item(P, cx, b[0], b[1], b[2], sm);
+            ok = (rate > P.rate_threshold && finite_d(rate)) ? 1 : 0;
+            atom = sm;
+        }
+    } else if (c == CAT_DIFF && st >= 1 && st <= 3) {
+        if (lane < 14 && sm == 0) {
+            const DiffCtx cx = diff_ctx(P, S, li, j, k, st, n_bonds, Tc);
+            rate = diff_item(P, cx, S.T[S.tidx(li + di, j + dj, k + dk)]);
+            ok = (rate > P.rate_threshold && finite_d(rate)) ? 1 : 0;
+            atom = st;
+        }
+    }
+    SlotPick pk;
+    pk.type = -1; pk.m = -1; pk.atom = 0; pk.rate = 0.0;
+    double cum = base;
+    bool found = false;
+#pragma unroll
+    for (int q = 0; q < 15; ++q) {
+        const int src = (q == 0) ? 14 : q - 1;                   // nucleation first, then the slots in order
+        const double rq = __shfl(rate, src);
+        const int oq = __shfl(ok, src), aq = __shfl(atom, src);
+        if (oq && !found) {
+            cum += rq;
+            pk.type = (src == 14) ? EV_NUC : (c == CAT_DIFF ? EV_DIFF : EV_ATT);
+            pk.m = (src == 14) ? -1 : src; pk.atom = aq; pk.rate = rq;      // remembers the last valid slot
+            if (cum >= r) found = true;
+        }
+    }
+    return pk;
+}
+
+struct DomPick {          // the chosen event of one box, before the uniforms are drawn
+    int32_t i, j, k;       // chosen voxel
+    int32_t type;          // EV_*; < 0: idle box
+    int32_t m, atom;       // neighbour slot (or -1), species
+    double rate;
 };
 
-// One wave per box: leaves = category sums of the window's voxels, LDS heap of NL = PT*PH*PH leaves, descent.
-// The per-voxel rate table (SlabView::vval) holds the EMPTY- or DIFF-category sum of EVERY owned voxel that owns events
-// (listed voxels: interface sums + ifc_cnt; other empty voxels: the nucleation rate by temperature), so a leaf is a
-// few loads (dep leaves: one exp, top plane only).
+// One wave per box: leaves = category sums of the window's voxels, LDS heap of NL = PT*PH*PH leaves built by the wave
+// (lane-local levels + shuffles, no block barriers), descent, slot scan inside the chosen voxel (slot_scan_wave).
+// The uniforms and the lattice write follow in k_domain_apply, one THREAD per box (fused into this kernel's lane 0 they
+// cost more: 32 768 waves each dragging a serial sincos / store tail, 97 vs 37 + 14 us).
+// The per-voxel rate table (SlabView::vval) holds the EMPTY- or
+// DIFF-category sum of EVERY owned voxel that owns events (listed voxels: interface sums + ifc_cnt; other empty voxels:
+// the nucleation rate by temperature), so a leaf is a few loads (dep leaves: one exp, top plane only).
 __global__ __launch_bounds__(64) void k_domain_pick(KParams P, const SlabView* __restrict__ slabs, int nslabs, int L,
-                                                    SuperCfg C, const StepState* __restrict__ ss, DomPick* __restrict__ picks)
+                                                    SuperCfg C, const StepState* __restrict__ ss, const double* __restrict__ ktab_g,
+                                                    DomPick* __restrict__ picks)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
-    const int d = C.d0 + blockIdx.x;            // global box index (keys the uniforms)
+    const int dl = blockIdx.x, d = C.d0 + dl;   // local / global box index (the global one keys the uniforms)
     if (ss->status) return;
     const int NL = C.PT * C.PH * C.PH;
     double* hs = reinterpret_cast<double*>(smem);             // [2*NL]
     uint8_t* hf = reinterpret_cast<uint8_t*>(hs + 2 * NL);    // [2*NL]
     uint8_t* lc = hf + 2 * NL;                                // [NL] leaf: event count | 128 if the voxel is a listed interface voxel
     for (int q = lane; q < NL; q += 64) { hs[NL + q] = 0.0; hf[NL + q] = 0; lc[q] = 0; }
-    __syncthreads();
-    const int64_t g = C.step0 + ss->cur;
+    const int64_t cur = ss->cur;
+    const int64_t g = C.step0 + cur;
     const int sec = (int)(g & 7);
     const int H = C.H, nb = C.nb;
     const int di = d / (nb * nb), dj = (d / nb) % nb, dk = d % nb;
     const int i0 = di * C.box + ((sec >> 2) & 1) * H, j0 = dj * C.box + ((sec >> 1) & 1) * H, k0 = dk * C.box + (sec & 1) * H;
+    __builtin_amdgcn_wave_barrier();
     for (int v = lane; v < H * H * H; v += 64) {
         const int kk = v % H, jj = (v / H) % H, ii = v / (H * H);
         const int i = i0 + ii, j = j0 + jj, k = k0 + kk;
@@ -80,22 +149,36 @@ __global__ __launch_bounds__(64) void k_domain_pick(KParams P, const SlabView* _
             }
         }
     }
-    __syncthreads();
-    for (int n = NL >> 1; n >= 1; n >>= 1) {
-        for (int idx = lane; idx < n; idx += 64) {
-            const int node = n + idx;
+    __builtin_amdgcn_wave_barrier();
+    // heap: the lane's NL/64 consecutive leaves fold locally, the six levels above by shuffles (a + b and b + a are the same
+    // double, so both lanes of a pair hold the node's value).  One wave: LDS operations complete in program order.
+    const int per = NL >> 6;                                   // >= 4
+    for (int w = per >> 1, lvl = NL >> 1; w >= 1; w >>= 1, lvl >>= 1)
+        for (int q = 0; q < w; ++q) {
+            const int node = lvl + w * lane + q;
             hs[node] = hs[2 * node] + hs[2 * node + 1];
             hf[node] = hf[2 * node] | hf[2 * node + 1];
         }
-        __syncthreads();
+    {
+        double v = hs[64 + lane];
+        int f = hf[64 + lane];
+#pragma unroll
+        for (int l = 0; l < 6; ++l) {
+            v = v + __shfl_xor(v, 1 << l);
+            f |= __shfl_xor(f, 1 << l);
+            if ((lane & ((2 << l) - 1)) == 0) {
+                const int node = (64 >> (l + 1)) + (lane >> (l + 1));
+                hs[node] = v; hf[node] = (uint8_t)f;
+            }
+        }
     }
-    if (lane != 0) return;
-    DomPick pk;
-    pk.i = pk.j = pk.k = 0; pk.cat = -1; pk.base = 0.0; pk.r = 0.0; pk.rate = 0.0; pk.simple = 0; pk.pad = 0;
+    __builtin_amdgcn_wave_barrier();
+    // descent (every lane walks the same path: LDS broadcasts)
+    int pi = 0, pj = 0, pkk = 0, cat = -1, simple = 0;
+    double base = 0.0, r = 0.0, leaf_rate = 0.0;
     const double R = hs[1];
     if (hf[1] && !(R < 1e-25) && finite_d(R)) {
-        const double r = counter_uniform(C.seed, (uint64_t)g, KEY_PICK | (uint64_t)d) * R;
-        double base = 0.0;
+        r = counter_uniform(C.seed, (uint64_t)g, KEY_PICK | (uint64_t)d) * R;
         int n = 1;
         while (n < NL) {
             const int l = 2 * n;
@@ -104,86 +187,78 @@ __global__ __launch_bounds__(64) void k_domain_pick(KParams P, const SlabView* _
         }
         const int q = n - NL;
         const int b = q / (C.PH * C.PH);
-        pk.i = i0 + b / 3; pk.cat = b % 3; pk.j = j0 + (q / C.PH) % C.PH; pk.k = k0 + q % C.PH;
-        pk.base = base; pk.r = r;
-        pk.rate = hs[NL + q];
-        pk.simple = (lc[q] == 1 && pk.cat != CAT_DIFF) ? 1 : 0;     // one event, voxel not listed (or a deposition leaf)
+        pi = i0 + b / 3; cat = b % 3; pj = j0 + (q / C.PH) % C.PH; pkk = k0 + q % C.PH;
+        leaf_rate = hs[NL + q];
+        simple = (lc[q] == 1 && cat != CAT_DIFF) ? 1 : 0;       // one event, voxel not listed (or a deposition leaf)
     }
-    picks[blockIdx.x] = pk;
+    DomPick pk;
+    pk.i = pi; pk.j = pj; pk.k = pkk; pk.type = -1; pk.m = -1; pk.atom = 0; pk.rate = 0.0;
+    if (cat >= 0) {                                              // wave-uniform
+        if (simple) {            // the deposition of this voxel / the nucleation of a bulk empty voxel: nothing to scan
+            pk.type = (cat == CAT_DEP) ? EV_DEP : EV_NUC;
+            pk.atom = (cat == CAT_DEP) ? 0 : 1;
+            pk.rate = leaf_rate;
+        } else {
+            int sl = 0;
+            for (int s = 0; s < nslabs; ++s) if (pi >= slabs[s].gi0 && pi < slabs[s].gi0 + slabs[s].nloc) sl = s;
+            const SlabView& S = slabs[sl];
+            const SlotPick sp = slot_scan_wave(P, S, ktab_g, pi - S.gi0 + 2, pj, pkk, cat, base, r, lane);     // one table entry: from global
+            pk.type = sp.type; pk.m = sp.m; pk.atom = sp.atom; pk.rate = sp.rate;
+        }
+    }
+    if (lane == 0) picks[dl] = pk;
 }
 
-// One thread per box: slot scan inside the chosen voxel, uniforms, lattice write (kmc_simulation.py:276-327).
-// Reads stay within +-2 of the chosen voxel and so do the writes of every other box's event (>= 5 away on
-// some axis): no box reads what another one writes, selection and application can share a kernel.
-__global__ __launch_bounds__(64) void k_domain_slot_apply(KParams P, const SlabView* __restrict__ slabs, int nslabs, int L, int D,
-                                                          SuperCfg C, StepState* ss, const DomPick* __restrict__ picks,
-                                                          const double* __restrict__ ktab_g, cetkmc_event* __restrict__ dom_events,
-                                                          unsigned long long* counters /* [0] executed, [1] nucleations */,
-                                                          cetkmc_event* log_events /* [n][D] or null */)
+// One thread per box: event record, uniforms, lattice write (kmc_simulation.py:276-327).  Reads stay within +-2 of the
+// chosen voxel and so do the writes of every other box's event (>= 5 away on some axis): no box reads what another writes.
+__global__ __launch_bounds__(64) void k_domain_apply(KParams P, const SlabView* __restrict__ slabs, int nslabs, int L, int D,
+                                                     SuperCfg C, StepState* ss, const DomPick* __restrict__ picks,
+                                                     cetkmc_event* __restrict__ dom_events,
+                                                     unsigned long long* counters /* per slot: [0] executed, [1] nucleations */,
+                                                     cetkmc_event* log_events /* [n][D] or null */)
 {
-    __shared__ double ktab[226];
-    for (int t = threadIdx.x; t < 225; t += 64) ktab[t] = ktab_g[t];
-    __syncthreads();
     if (ss->status) return;
     const int dl = blockIdx.x * 64 + threadIdx.x;       // local box
     if (dl >= D) return;
     const int d = C.d0 + dl;                            // global box index (keys the uniforms)
-    const int64_t g = C.step0 + ss->cur;
+    const int64_t cur = ss->cur;
+    const int64_t g = C.step0 + cur;
+    const DomPick pk = picks[dl];
     cetkmc_event ev;
-    ev.type = -1;
+    ev.type = pk.type;
     ev.pos[0] = ev.pos[1] = ev.pos[2] = 0;
     ev.target[0] = ev.target[1] = ev.target[2] = -1;
     ev.atom = 0; ev.rate = 0.0; ev.dep_rank = -1; ev.theta = 0.0; ev.phi = 0.0;
-    const DomPick pk = picks[dl];
-    if (pk.cat >= 0) {
-        const int i = pk.i, j = pk.j, k = pk.k, c = pk.cat;
-        const double r = pk.r;
-        int sl = 0;
-        for (int s = 0; s < nslabs; ++s) if (i >= slabs[s].gi0 && i < slabs[s].gi0 + slabs[s].nloc) sl = s;
-        const SlabView& S = slabs[sl];
-        const int li = i - S.gi0 + 2;
-        int p_type = -1, p_m = -1, p_atom = 0;
-        double p_rate = 0.0;
-        if (pk.simple) {            // the deposition of this voxel / the nucleation of a bulk empty voxel: nothing to scan
-            p_type = (c == CAT_DEP) ? EV_DEP : EV_NUC;
-            p_atom = (c == CAT_DEP) ? 0 : 1;
-            p_rate = pk.rate;
-        } else {
-            const int st = S.state[S.sidx(li, j, k)];
-            double cum = pk.base;
-            bool found = false;
-            auto nbs = [&](int mm) -> int { return S.state[S.sidx(li + nbi_rt(mm), j + nbj_rt(mm), k + nbk_rt(mm))]; };
-            auto emit = [&](int cat, int type, double rate, int m, int atom) {
-                if (cat != c || found) return;
-                cum += rate;
-                p_type = type; p_m = m; p_atom = atom; p_rate = rate;   // remembers the last valid slot
-                if (cum >= r) found = true;
-            };
-            eval_voxel(P, S, ktab, li, i, j, k, st, S.T[S.tidx(li, j, k)], nbs, emit);
-        }
-        ev.type = p_type;
+    if (pk.type >= 0) {
+        const int i = pk.i, j = pk.j, k = pk.k;
         ev.pos[0] = i; ev.pos[1] = j; ev.pos[2] = k;
-        ev.atom = p_atom; ev.rate = p_rate;
-        if (p_m >= 0) {
-            const int ai = nbi_rt(p_m), aj = nbj_rt(p_m), ak = nbk_rt(p_m);
+        ev.atom = pk.atom; ev.rate = pk.rate;
+        if (pk.m >= 0) {
+            int sl = 0;
+            for (int s = 0; s < nslabs; ++s) if (i >= slabs[s].gi0 && i < slabs[s].gi0 + slabs[s].nloc) sl = s;
+            const SlabView& S = slabs[sl];
+            const int li = i - S.gi0 + 2;
+            const int ai = nbi_rt(pk.m), aj = nbj_rt(pk.m), ak = nbk_rt(pk.m);
             ev.target[0] = i + ai; ev.target[1] = j + aj; ev.target[2] = k + ak;
-            const int64_t src = (p_type == EV_DIFF) ? S.tidx(li, j, k) : S.tidx(li + ai, j + aj, k + ak);
+            const int64_t src = (pk.type == EV_DIFF) ? S.tidx(li, j, k) : S.tidx(li + ai, j + aj, k + ak);
             ev.theta = S.theta[src]; ev.phi = S.phi[src];
         }
-        if (p_type == EV_DEP)
+        if (pk.type == EV_DEP)
             ev.atom = dep_species(P, counter_uniform(C.seed, (uint64_t)g, (uint64_t)j * (uint64_t)L + (uint64_t)k));
-        if (p_type == EV_DEP || p_type == EV_NUC) {
+        if (pk.type == EV_DEP || pk.type == EV_NUC) {
             ev.theta = 0.0 + (3.141592653589793 - 0.0) * counter_uniform(C.seed, (uint64_t)g, KEY_THETA | (uint64_t)d);
             ev.phi = 0.0 + (6.283185307179586 - 0.0) * counter_uniform(C.seed, (uint64_t)g, KEY_PHI | (uint64_t)d);
         }
     }
     dom_events[dl] = ev;
-    if (log_events) log_events[ss->cur * (int64_t)D + dl] = ev;
+    if (log_events) log_events[cur * (int64_t)D + dl] = ev;
     if (ev.type < 0) return;
     const int mk = (C.defect_fraction > 0.0 && counter_uniform(C.seed, (uint64_t)g, KEY_DEFECT | (uint64_t)d) < C.defect_fraction) ? 1 : 0;
     apply_event(slabs, nslabs, ev, mk);
-    atomicAdd(&counters[0], 1ull);
-    if (ev.type == EV_NUC) atomicAdd(&counters[1], 1ull);
+    // (a block's 64 lanes share a slot: the compiler folds them into one atomic per wave)
+    unsigned long long* slot = counters + (size_t)(blockIdx.x % SUPER_CNT_SLOTS) * SUPER_CNT_STRIDE;
+    atomicAdd(&slot[0], 1ull);
+    if (ev.type == EV_NUC) atomicAdd(&slot[1], 1ull);
 }
 
 // Across ranks: the events of the neighbour ranks' boundary box layers (nb^2 boxes each, received after their own
@@ -242,7 +317,7 @@ __global__ __launch_bounds__(256) CETKMC_TOUCH_ATTR void k_domain_touch(KParams 
         if (hit) S.ifc_in[t] = 1;
         if (!hit && !S.ifc_in[t]) continue;
         S.ifc_code[t] = code;
-        const int st = (code >> 30) ? 4 : (int)((code >> 28) & 3u);
+        const int st = code_state(code);
         const double Tc = pymax(S.T[t], 1.0);
         double sum = 0.0;
         int cnt = 0;
@@ -292,14 +367,23 @@ __global__ __launch_bounds__(256) void k_ifc_relist(SlabView S, const StepState*
     }
 }
 
-__global__ void k_super_commit(StepState* ss, unsigned long long* counters, double* log_total, int64_t* log_exec)
+__global__ __launch_bounds__(64) void k_super_commit(StepState* ss, unsigned long long* counters, double* log_total, int64_t* log_exec)
 {
     if (ss->status) return;
+    const int lane = threadIdx.x;
+    long long ex = 0, nu = 0;
+    for (int q = lane; q < SUPER_CNT_SLOTS; q += 64) {
+        unsigned long long* slot = counters + (size_t)q * SUPER_CNT_STRIDE;
+        ex += (long long)slot[0]; nu += (long long)slot[1];
+        slot[0] = 0; slot[1] = 0;
+    }
+#pragma unroll
+    for (int l = 0; l < 6; ++l) { ex += __shfl_xor(ex, 1 << l); nu += __shfl_xor(nu, 1 << l); }
+    if (lane != 0) return;
     const int64_t s = ss->cur;
     if (log_total) log_total[s] = ss->total;
-    if (log_exec) log_exec[s] = (int64_t)counters[0];
-    ss->nuc_count += (int64_t)counters[1];
-    counters[0] = 0; counters[1] = 0;
+    if (log_exec) log_exec[s] = ex;
+    ss->nuc_count += nu;
     ss->cur = s + 1;
 }
 
