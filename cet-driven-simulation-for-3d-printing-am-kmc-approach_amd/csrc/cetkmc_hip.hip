@@ -87,6 +87,8 @@ struct Slab {
     SlabView v{};
     uint8_t* prev = nullptr;
     double* Tbuf[2] = {nullptr, nullptr};
+    double* vvalbuf[2] = {nullptr, nullptr};     // rate table of Tbuf[b] (the pair is flipped together)
+    double* depbuf[2] = {nullptr, nullptr};      // plane L-1 deposition rates of Tbuf[b]
     size_t nS = 0, nT = 0, nC = 0;   // bytes of a u8 array, doubles of an f64 array, u16s of the class array
 };
 
@@ -139,6 +141,18 @@ struct Handle {
     cetkmc_host_comm hc{};       // host-relay transport (cetkmc_create_rank_host); used when comm is null
     std::vector<char> hc_stage;
     cetkmc_counters cnt{};       // cetkmc_get_counters: work issued / bytes moved / per-phase device time
+    // look-ahead temperature update: T(n+1) + its rate table computed on stream2 while the 19 steps between two updates run
+    struct Spec {
+        bool valid = false;
+        int64_t g = -1;          // global step of the update it stands for
+        int laser = 0, use_latent = 0, scrub = 0;
+        double dt = 0.0;
+        const double* d_q = nullptr;
+    } spec;
+    int thermal_ahead = 0;       // option "thermal_lookahead": off by default -- measured slower on one GPU:
+                                 // the look-ahead kernels run right behind the update, beside the next sweeps, which they slow down
+                                 // by more than the update costs (both are memory bound, and they evict the sweep's working set)
+    hipEvent_t ev_main = nullptr, ev_spec = nullptr;
 };
 
 KParams make_kparams(const cetkmc_params& p)
@@ -180,7 +194,7 @@ int push_views(Handle* h)
 {
     for (int par = 0; par < 2; ++par) {
         std::vector<SlabView> v;
-        for (auto& s : h->slabs) { SlabView x = s.v; x.T = s.Tbuf[par]; v.push_back(x); }
+        for (auto& s : h->slabs) { SlabView x = s.v; x.T = s.Tbuf[par]; x.vval = s.vvalbuf[par]; x.dep_val = s.depbuf[par]; v.push_back(x); }
         HIPCHK(hipMemcpyAsync(h->d_views[par], v.data(), v.size() * sizeof(SlabView), hipMemcpyHostToDevice, h->stream));
     }
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -219,10 +233,17 @@ int create_common(const cetkmc_params* p, int L, const std::vector<std::pair<int
     h->shmem_stream = (size_t)STREAM_SLOTS * (SWEEP_TJ + 4) * h->pitchC;
     if (h->shmem_stream > 64 * 1024 || (SWEEP_TJ + 4) * h->pitchC > 16 * 256 * STREAM_MAXPF) { delete h; return fail("L too large for the LDS ring"); }
     h->dev = dev; h->G = G; h->my_first = my_first;
-    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    {   // the stepping loop's stream at the highest priority, the look-ahead stream at the lowest: its workgroups are
+        // dispatched into what the main stream leaves free (the one-block selection kernels leave almost everything)
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, greatest));
+        HIPCHK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, least));
+    }
     HIPCHK(hipEventCreate(&h->ev0));
     HIPCHK(hipEventCreate(&h->ev1));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_spec, hipEventDisableTiming));
     h->own_i0 = ranges.front().first;
     h->own_i1 = ranges.back().first + ranges.back().second;
     for (auto& r : ranges) {
@@ -252,16 +273,19 @@ int create_common(const cetkmc_params* p, int L, const std::vector<std::pair<int
         HIPCHK(hipMemsetAsync(s.v.theta, 0, s.nT * sizeof(double), h->stream));
         HIPCHK(hipMemsetAsync(s.v.phi, 0, s.nT * sizeof(double), h->stream));
         HIPCHK(hipMalloc((void**)&s.v.ovec, 3 * s.nT * sizeof(double)));
-        HIPCHK(hipMalloc((void**)&s.v.vval, s.nT * sizeof(double)));
-        HIPCHK(hipMalloc((void**)&s.v.dep_val, (size_t)L * h->pitchT * sizeof(double)));
-        HIPCHK(hipMemsetAsync(s.v.dep_val, 0, (size_t)L * h->pitchT * sizeof(double), h->stream));
+        for (int b = 0; b < 2; ++b) {
+            HIPCHK(hipMalloc((void**)&s.vvalbuf[b], s.nT * sizeof(double)));
+            HIPCHK(hipMemsetAsync(s.vvalbuf[b], 0, s.nT * sizeof(double), h->stream));
+            HIPCHK(hipMalloc((void**)&s.depbuf[b], (size_t)L * h->pitchT * sizeof(double)));
+            HIPCHK(hipMemsetAsync(s.depbuf[b], 0, (size_t)L * h->pitchT * sizeof(double), h->stream));
+        }
+        s.v.vval = s.vvalbuf[0]; s.v.dep_val = s.depbuf[0];
         HIPCHK(hipMalloc((void**)&s.v.ifc_cnt, s.nT));
         HIPCHK(hipMalloc((void**)&s.v.ifc_in, s.nT));
         HIPCHK(hipMalloc((void**)&s.v.ifc_code, s.nT * sizeof(uint32_t)));
         HIPCHK(hipMemsetAsync(s.v.ifc_code, 0xFF, s.nT * sizeof(uint32_t), h->stream));
         HIPCHK(hipMalloc((void**)&s.v.ifc_list, (size_t)r.second * L * L * sizeof(uint32_t)));
         HIPCHK(hipMalloc((void**)&s.v.ifc_n, sizeof(int)));
-        HIPCHK(hipMemsetAsync(s.v.vval, 0, s.nT * sizeof(double), h->stream));
         HIPCHK(hipMemsetAsync(s.v.ifc_cnt, 0, s.nT, h->stream));
         HIPCHK(hipMemsetAsync(s.v.ifc_in, 0, s.nT, h->stream));
         HIPCHK(hipMemsetAsync(s.v.ifc_n, 0, sizeof(int), h->stream));
@@ -293,7 +317,13 @@ int create_common(const cetkmc_params* p, int L, const std::vector<std::pair<int
     return 0;
 }
 
-SlabView view_of(Handle* h, int s) { SlabView v = h->slabs[s].v; v.T = h->slabs[s].Tbuf[h->cur]; return v; }
+SlabView view_of(Handle* h, int s, int par = -1)
+{
+    if (par < 0) par = h->cur;
+    SlabView v = h->slabs[s].v;
+    v.T = h->slabs[s].Tbuf[par]; v.vval = h->slabs[s].vvalbuf[par]; v.dep_val = h->slabs[s].depbuf[par];
+    return v;
+}
 
 // per-call device allocation released on every return path
 template <class T>
@@ -460,18 +490,23 @@ int launch_interface(Handle* h, bool batch, hipStream_t st, bool long_list = fal
 // per-voxel rate table + plane L-1 deposition rates from the current temperature field (stale after an upload of T, a
 // temperature update or a parameter change); it overwrites the listed voxels' entries too, so the interface kernel
 // has to follow
-int ensure_table(Handle* h, hipStream_t st, const StepState* ss)
+int launch_table(Handle* h, hipStream_t st, const StepState* ss, int par)
 {
-    if (h->table_fresh) return 0;
     const double K0 = host_k_eff(h->p, 0, 0);
     for (size_t s = 0; s < h->slabs.size(); ++s) {
-        SlabView v = view_of(h, (int)s);
+        SlabView v = view_of(h, (int)s, par);
         const int64_t pairs = (int64_t)v.nloc * v.L * (v.pitchT / 2);
         hipLaunchKernelGGL(k_rate_table, dim3((unsigned)std::min<int64_t>((pairs + 255) / 256, 8192)), dim3(256), 0, st, h->kp, v, K0, ss);
         h->cnt.alg_bytes_table += (int64_t)16 * v.nloc * v.L * v.L;     // T read, table entry written
     }
     HIPCHK(hipGetLastError());
     ++h->cnt.table_updates;
+    return 0;
+}
+int ensure_table(Handle* h, hipStream_t st, const StepState* ss)
+{
+    if (h->table_fresh) return 0;
+    CHK(launch_table(h, st, ss, h->cur));
     h->table_fresh = true;
     h->ifc_fresh = false;
     return 0;
@@ -670,15 +705,16 @@ int comm_exchange(Handle* h, const void* send_lo, void* recv_lo, const void* sen
     return 0;
 }
 
-int exchange_T_halo(Handle* h, int buf)
+int exchange_T_halo(Handle* h, int buf, hipStream_t st = nullptr)
 {
+    if (!st) st = h->stream;
     const size_t plane = (size_t)h->L * h->pitchT;   // doubles
     for (size_t s = 0; s + 1 < h->slabs.size(); ++s) {
         Slab& a = h->slabs[s];
         Slab& b = h->slabs[s + 1];
         // a's top two owned planes -> b's lower halo; b's bottom two owned planes -> a's upper halo
-        HIPCHK(hipMemcpyAsync(b.Tbuf[buf], a.Tbuf[buf] + plane * a.v.nloc, 2 * plane * 8, hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(a.Tbuf[buf] + plane * (a.v.nloc + 2), b.Tbuf[buf] + plane * 2, 2 * plane * 8, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(b.Tbuf[buf], a.Tbuf[buf] + plane * a.v.nloc, 2 * plane * 8, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(a.Tbuf[buf] + plane * (a.v.nloc + 2), b.Tbuf[buf] + plane * 2, 2 * plane * 8, hipMemcpyDeviceToDevice, st));
     }
     if (multi_rank(h) && h->nranks > 1) {
         // my bottom / top two owned planes -> the neighbours' halos; theirs -> mine (2 L^2 doubles each way, one xGMI link per side)
@@ -728,6 +764,77 @@ int launch_thermal(Handle* h, double dt, int laser, const double* d_q, int use_l
     return 0;
 }
 
+ThermalCfg thermal_cfg(Handle* h, double dt, int laser, int use_latent, int scrub)
+{
+    ThermalCfg C{};
+    C.dt = dt; C.alpha = h->p.alpha; C.inv_dx2 = h->p.inv_dx2; C.clip_lo = h->p.T_clip_lo; C.clip_hi = h->p.T_clip_hi;
+    C.T_nan = h->p.T_nan; C.rho_cp = h->p.rho_cp; C.latent_coef = h->p.latent_coef;
+    C.laser = laser; C.use_latent = use_latent; C.scrub = scrub; C.ni = h->therm_ni;
+    return C;
+}
+
+// Look-ahead: the temperature update that global step g will perform, and the rate table of its result, computed NOW on
+// stream2 from the current field into the other buffer pair -- without the latent-heat term (k_thermal_fix adds it at
+// the update, for the few voxels it concerns).  The current field does not change until then, so this is the update's
+// own arithmetic, merely scheduled into the idle time of the 19 steps in between (the one-block selection kernels
+// leave the chip almost empty).  Single process only (the T halo of a multi-rank run travels on the main stream).
+int launch_thermal_ahead(Handle* h, int64_t g, double dt, int laser, const double* d_q, int use_latent, int scrub)
+{
+    h->spec.valid = false;
+    if (!h->thermal_ahead || h->thermal_variant != 1 || (multi_rank(h) && h->nranks > 1)) return 0;
+    const ThermalCfg C = thermal_cfg(h, dt, laser, 0, scrub);
+    const int nxt = h->cur ^ 1;
+    HIPCHK(hipEventRecord(h->ev_main, h->stream));
+    HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_main, 0));
+    for (size_t s = 0; s < h->slabs.size(); ++s) {
+        SlabView v = view_of(h, (int)s);
+        dim3 grid((h->L + THERM_KT - 1) / THERM_KT, (h->L + THERM_TJ - 1) / THERM_TJ, (v.nloc + h->therm_ni - 1) / h->therm_ni);
+        hipLaunchKernelGGL(k_thermal_march, grid, dim3(256), 0, h->stream2, v, (const double*)h->slabs[s].Tbuf[h->cur],
+                           h->slabs[s].Tbuf[nxt], h->slabs[s].prev, d_q, C, (const StepState*)h->d_ss);
+    }
+    HIPCHK(hipGetLastError());
+    CHK(exchange_T_halo(h, nxt, h->stream2));
+    CHK(launch_table(h, h->stream2, (const StepState*)h->d_ss, nxt));
+    HIPCHK(hipEventRecord(h->ev_spec, h->stream2));
+    h->spec.valid = true; h->spec.g = g; h->spec.laser = laser; h->spec.use_latent = use_latent; h->spec.scrub = scrub;
+    h->spec.dt = dt; h->spec.d_q = d_q;
+    return 0;
+}
+
+// the temperature update of global step g inside a batch: the look-ahead result if it stands for exactly this update
+// (then only k_thermal_fix runs on the main stream), else the synchronous kernels
+int thermal_step(Handle* h, int64_t g, double dt, int laser, const double* d_q, int use_latent, int scrub)
+{
+    Handle::Spec& sp = h->spec;
+    if (!(sp.valid && sp.g == g && sp.laser == laser && sp.use_latent == use_latent && sp.scrub == scrub && sp.dt == dt && sp.d_q == d_q)) {
+        if (sp.valid) { HIPCHK(hipStreamSynchronize(h->stream2)); sp.valid = false; }     // a stale look-ahead still owns the other buffers
+        return launch_thermal(h, dt, laser, d_q, use_latent, scrub, true);
+    }
+    sp.valid = false;
+    const ThermalCfg C = thermal_cfg(h, dt, laser, use_latent, scrub);
+    const int nxt = h->cur ^ 1;
+    const double K0 = host_k_eff(h->p, 0, 0);
+    ++h->cnt.thermal_updates;
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_spec, 0));
+    for (size_t s = 0; s < h->slabs.size(); ++s) {
+        Slab& sl = h->slabs[s];
+        SlabView v = view_of(h, (int)s);
+        h->cnt.alg_bytes_thermal += (int64_t)16 * v.nloc * h->L * h->L;
+        hipLaunchKernelGGL(k_thermal_fix, dim3(1024), dim3(256), 0, h->stream, h->kp, v, (const double*)sl.Tbuf[h->cur], sl.Tbuf[nxt],
+                           sl.prev, d_q, C, (const StepState*)h->d_ss, (const double*)sl.vvalbuf[h->cur], sl.vvalbuf[nxt],
+                           (const double*)sl.depbuf[h->cur], sl.depbuf[nxt], K0);
+        if (laser && use_latent)
+            hipLaunchKernelGGL(k_clear_row_flags, dim3(64), dim3(256), 0, h->stream, v, (const StepState*)h->d_ss);
+    }
+    HIPCHK(hipGetLastError());
+    if (h->slabs.size() > 1) CHK(exchange_T_halo(h, nxt));      // the recomputed voxels may sit in a neighbour slab's halo
+    h->cur = nxt;
+    h->swept = false;
+    h->table_fresh = true;       // computed ahead with the field
+    h->ifc_fresh = false;        // the listed voxels' entries are not: the interface kernel follows
+    return 0;
+}
+
 template <class T>
 int grow(T** p, size_t* cap, size_t need)
 {
@@ -745,12 +852,13 @@ void destroy_impl(Handle* h)
     if (!h) return;
     (void)hipSetDevice(h->dev);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     for (auto& s : h->slabs) {
         (void)hipFree(s.v.state); (void)hipFree(s.v.defects); (void)hipFree(s.prev); (void)hipFree(s.v.row_chg); (void)hipFree(s.v.cls);
         (void)hipFree(s.Tbuf[0]); (void)hipFree(s.Tbuf[1]); (void)hipFree(s.v.theta); (void)hipFree(s.v.phi); (void)hipFree(s.v.ovec);
         (void)hipFree(s.v.rowsum); (void)hipFree(s.v.rowcnt);
-        (void)hipFree(s.v.vval); (void)hipFree(s.v.dep_val); (void)hipFree(s.v.ifc_cnt); (void)hipFree(s.v.ifc_in); (void)hipFree(s.v.ifc_code); (void)hipFree(s.v.ifc_list); (void)hipFree(s.v.ifc_n);
+        (void)hipFree(s.vvalbuf[0]); (void)hipFree(s.vvalbuf[1]); (void)hipFree(s.depbuf[0]); (void)hipFree(s.depbuf[1]); (void)hipFree(s.v.ifc_cnt); (void)hipFree(s.v.ifc_in); (void)hipFree(s.v.ifc_code); (void)hipFree(s.v.ifc_list); (void)hipFree(s.v.ifc_n);
     }
     void* ccp[] = {h->d_cc_parent, h->d_cc_roots, h->d_cc_cid, h->d_cc_labels, h->d_cc_stats, h->d_cc_n};
     for (void* p : ccp) if (p) (void)hipFree(p);
@@ -761,6 +869,8 @@ void destroy_impl(Handle* h)
     for (auto e : h->prof) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev_main) (void)hipEventDestroy(h->ev_main);
+    if (h->ev_spec) (void)hipEventDestroy(h->ev_spec);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -889,6 +999,7 @@ int cetkmc_set_option(void* handle, const char* key, int64_t value)
         h->therm_ni = (int)value;
         return 0;
     }
+    if (!strcmp(key, "thermal_lookahead")) { h->thermal_ahead = value ? 1 : 0; return 0; }
     if (!strcmp(key, "thermal_variant")) {
         if (value < 0 || value > 1) return fail("thermal_variant must be 0 (simple) or 1 (marching, default)");
         h->thermal_variant = (int)value;
@@ -1196,8 +1307,11 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
         ++res->full_sweeps;
         if (a->profile == 2) { was_full[s] = 1; HIPCHK(hipEventRecord(pev(s, 0), h->stream)); }
         if (therm) {
-            if (a->thermal_mode == 1) CHK(launch_thermal(h, a->thermal_dt, 0, nullptr, 0, 1, true));
-            else { CHK(launch_thermal(h, a->thermal_dt, 1, h->d_q + (size_t)q_idx * L2, a->use_latent, 1, true)); ++q_idx; }
+            const int laser = a->thermal_mode == 2 ? 1 : 0, latent = laser ? a->use_latent : 0;
+            CHK(thermal_step(h, g, a->thermal_dt, laser, laser ? h->d_q + (size_t)q_idx * L2 : nullptr, latent, 1));
+            q_idx += laser;
+            if (g + 20 < a->step0 + n)      // the next update lies inside this batch (its source plane is on the device): look ahead
+                CHK(launch_thermal_ahead(h, g + 20, a->thermal_dt, laser, laser ? h->d_q + (size_t)q_idx * L2 : nullptr, latent, 1));
             if (a->profile == 2) was_thermal[s] = 1;
         }
         if (a->profile == 2) CHK(launch_sweep(h, true, pev(s, 2), pev(s, 3), false, pev(s, 1), pev(s, 4)));
@@ -1212,6 +1326,7 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipMemcpyAsync(&ss, h->d_ss, sizeof ss, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->spec.valid) { HIPCHK(hipStreamSynchronize(h->stream2)); h->spec.valid = false; }      // never outlives its batch
     res->steps_done = ss.cur; res->status = ss.status; res->np_used = ss.np_pos; res->q_used = q_idx;
     res->nucleation_count = ss.nuc_count;
     float ms = 0.f;
@@ -1347,8 +1462,11 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
         const int64_t g = a->step0 + s;
         const bool therm = a->thermal_mode && g % 20 == 0;
         if (therm) {
-            if (a->thermal_mode == 1) CHK(launch_thermal(h, a->thermal_dt, 0, nullptr, 0, 1, true));
-            else { CHK(launch_thermal(h, a->thermal_dt, 1, h->d_q + (size_t)q_idx * L2, a->use_latent, 1, true)); ++q_idx; }
+            const int laser = a->thermal_mode == 2 ? 1 : 0, latent = laser ? a->use_latent : 0;
+            CHK(thermal_step(h, g, a->thermal_dt, laser, laser ? h->d_q + (size_t)q_idx * L2 : nullptr, latent, 1));
+            q_idx += laser;
+            if (g + 20 < a->step0 + n)      // the next update lies inside this batch (its source plane is on the device): look ahead
+                CHK(launch_thermal_ahead(h, g + 20, a->thermal_dt, laser, laser ? h->d_q + (size_t)q_idx * L2 : nullptr, latent, 1));
         }
         // interface sums: the list kernel after a temperature update / when something else made them stale (list
         // rebuilt in address order first: k_domain_touch flags new interface voxels without appending them); otherwise
@@ -1379,6 +1497,7 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipMemcpyAsync(&ss, h->d_ss, sizeof ss, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->spec.valid) { HIPCHK(hipStreamSynchronize(h->stream2)); h->spec.valid = false; }
     res->steps_done = ss.cur; res->status = ss.status; res->np_used = 0; res->q_used = q_idx;
     res->nucleation_count = ss.nuc_count;
     float ms = 0.f;

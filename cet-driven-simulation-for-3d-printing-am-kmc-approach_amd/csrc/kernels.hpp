@@ -1544,6 +1544,76 @@ __global__ void k_clear_row_flags(SlabView S, const StepState* __restrict__ ss)
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) S.row_chg[q] = 0;
 }
 
+// thermal_solver.py:36-105 for ONE voxel (same expression order as k_thermal / k_thermal_march), with the latent-heat
+// indicator dF01 (0 or 1) given by the caller
+__device__ __forceinline__ double thermal_voxel(const SlabView& S, const double* __restrict__ Tin, const double* __restrict__ q_top,
+                                                const ThermalCfg& C, int li, int i, int j, int k, double dF01)
+{
+    const int L = S.L;
+    const int im = (i > 0 ? i - 1 : 0) - (S.gi0 - 2), ip = (i < L - 1 ? i + 1 : L - 1) - (S.gi0 - 2);
+    const int jm = j > 0 ? j - 1 : 0, jp = j < L - 1 ? j + 1 : L - 1;
+    const int km = k > 0 ? k - 1 : 0, kp = k < L - 1 ? k + 1 : L - 1;
+    const double tc = scrub_T(Tin[S.tidx(li, j, k)], C.T_nan, C.scrub);
+    const double d0 = tc * -2.0 + (scrub_T(Tin[S.tidx(im, j, k)], C.T_nan, C.scrub) + scrub_T(Tin[S.tidx(ip, j, k)], C.T_nan, C.scrub));
+    const double d1 = tc * -2.0 + (scrub_T(Tin[S.tidx(li, jm, k)], C.T_nan, C.scrub) + scrub_T(Tin[S.tidx(li, jp, k)], C.T_nan, C.scrub));
+    const double d2 = tc * -2.0 + (scrub_T(Tin[S.tidx(li, j, km)], C.T_nan, C.scrub) + scrub_T(Tin[S.tidx(li, j, kp)], C.T_nan, C.scrub));
+    const double lap = ((d0 + d1) + d2) * C.inv_dx2;
+    const double qv = (i == L - 1) ? q_top[(int64_t)j * L + k] : 0.0;
+    const double qterm = (qv != 0.0) ? qv / C.rho_cp : 0.0;
+    const double dtm = C.dt > 1e-12 ? C.dt : 1e-12;
+    const double dF = (dF01 != 0.0) ? 1.0 / dtm : 0.0;
+    const double dTdt = C.alpha * lap + qterm + C.latent_coef * dF;
+    const double nt = tc + C.dt * dTdt;
+    double v = nt < C.clip_lo ? C.clip_lo : nt;
+    v = v > C.clip_hi ? C.clip_hi : v;
+    return v;
+}
+
+// Look-ahead temperature update (laser mode with the latent-heat term): T(n+1) and its rate table were computed ahead of
+// time on a second stream WITHOUT the latent-heat term, which only differs at voxels that turned from empty to occupied
+// since the previous update (thermal_solver.py:98-99) -- a handful per 20 steps, all in rows flagged by write_site().
+// This kernel, launched at the update itself, recomputes exactly those voxels (temperature, table entry, deposition
+// rate) from the old field, brings prev_state level with state on the flagged rows and clears the flags.  A batch that
+// has terminated leaves T alone (kmc_simulation.py:260-262 breaks before the next update): the old field, table and
+// deposition rates are copied over the speculative ones.
+__global__ __launch_bounds__(256) void k_thermal_fix(KParams P, SlabView S, const double* __restrict__ Tin, double* __restrict__ Tout,
+                                                     uint8_t* __restrict__ prev_state, const double* __restrict__ q_top, ThermalCfg C,
+                                                     const StepState* __restrict__ ss, const double* __restrict__ vv_old,
+                                                     double* __restrict__ vv_new, const double* __restrict__ dep_old,
+                                                     double* __restrict__ dep_new, double K0)
+{
+    const int L = S.L;
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+    if (ss && ss->status) {
+        const int64_t nT = (int64_t)(S.nloc + 4) * L * S.pitchT;
+        for (int64_t q = gtid; q < nT; q += nthr) { Tout[q] = Tin[q]; vv_new[q] = vv_old[q]; }
+        for (int64_t q = gtid; q < (int64_t)L * S.pitchT; q += nthr) dep_new[q] = dep_old[q];
+        return;
+    }
+    if (!(C.laser && C.use_latent)) return;                // no latent-heat term: the look-ahead field is already exact
+    const int lp_top = L - 1 - S.gi0;
+    // one wave per row (the flag test is wave-uniform), lanes over k
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = gtid >> 6, nwaves = nthr >> 6;
+    for (int64_t r = wave; r < (int64_t)S.nloc * L; r += nwaves) {
+        const int lp = (int)(r / L), j = (int)(r - (int64_t)lp * L), li = lp + 2;
+        if (!S.row_chg[(int64_t)li * L + j]) continue;
+        for (int k = lane; k < L; k += 64) {
+            const int64_t sc = S.sidx(li, j, k);
+            const int st = S.state[sc], pv = prev_state[sc];
+            if (pv == 0 && st != 0) {
+                const double v = thermal_voxel(S, Tin, q_top, C, li, S.gi0 + lp, j, k, 1.0);
+                const int64_t c = S.tidx(li, j, k);
+                Tout[c] = v;
+                vv_new[c] = nuc_bulk(P.T_melt, P.delta_T_c, P.kT, P.I0, P.rate_threshold, K0, v);
+                if (lp == lp_top) dep_new[(int64_t)j * S.pitchT + k] = dep_rate(P, pymax(v, 1.0));
+            }
+            if (pv != st) prev_state[sc] = (uint8_t)st;
+        }
+    }
+    // every flag of the slab (halo rows included) is dropped by k_clear_row_flags, launched behind this kernel
+}
+
 // k_thermal_march: same arithmetic as k_thermal, 2.5-D blocked.  One block owns THERM_TJ rows x 256
 // columns and marches over THERM_NI planes: the planes i-1, i, i+1 of its own voxels live in registers
 // (8 voxels per thread), plane i additionally in an LDS tile with a one-voxel rim for the j+-1 / k+-1

@@ -191,8 +191,9 @@ int cetkmc_set_params(void* handle, const cetkmc_params* p);
 int cetkmc_sync(void* handle);
 /* tuning / A-B switches: "sweep_variant" 0 = simple kernel, 1 = streaming kernel + per-voxel rate table (default),
  * 2 = streaming kernel that recomputes the nucleation rates in every sweep; "interface_every_step" 1 = evaluate the
- * whole interface list before every full sweep instead of only after a temperature update; "thermal_variant",
- * "thermal_planes_per_block" */
+ * whole interface list before every full sweep instead of only after a temperature update; "thermal_lookahead" 1 = the next
+ * temperature update of a batch and its rate table are computed ahead on a second stream (single process; same bits;
+ * default 0: measured slower); "thermal_variant", "thermal_planes_per_block" */
 int cetkmc_set_option(void* handle, const char* key, int64_t value);
 /* planes [*i0,*i1) owned by this handle (whole lattice unless created with create_rank) */
 int cetkmc_owned_planes(void* handle, int* i0, int* i1);

@@ -740,3 +740,39 @@ def test_config5_workload_at_size(oracle_mod):
     np.random.seed(7)
     mask_host = defects_mod.track_defects(lat.state.astype(np.int64), lat.state.astype(np.int64), L, lat.T)
     assert np.array_equal(mask_dev != 0, mask_host != 0)
+
+
+@pytest.mark.parametrize("n_slabs,thermal_mode", [(1, 2), (3, 2), (1, 1)])
+def test_thermal_lookahead_option_identical(n_slabs, thermal_mode):
+    """thermal_lookahead=1: the next temperature update of a batch and its rate table are computed ahead on a second
+    stream without the latent-heat term; at the update k_thermal_fix recomputes the voxels the term concerns.  Must not
+    change a bit (events, totals, T, every field), also when the batch terminates early and across batches."""
+    import cetkmc
+    from cetkmc import synthetic
+    L, n = 48, 130
+    st, th, ph, T, df = synthetic.planes(L, 0, L, seed=5)
+    rs = np.random.RandomState(6)
+    idx = rs.randint(0, L, (300, 3))
+    st[idx[:, 0], idx[:, 1], idx[:, 2]] = rs.randint(1, 5, 300)
+    u_pick, u_def, u_np = rs.random_sample(n), rs.random_sample(n), rs.random_sample(2 * n + 2)
+    outs = []
+    for la in (0, 1):
+        e = cetkmc.Engine(L, impurity_c=0.2, n_slabs=n_slabs)
+        e.set_option("thermal_lookahead", la)
+        e.upload_planes(0, L, st, th, ph, T, df)
+        e.set_prev_state(None)
+        res, pos, step = [], 0, 3
+        for nb in (47, 83):                        # two batches, starting off the 20-step cadence
+            q = synthetic.laser_planes(L, step, nb) if thermal_mode == 2 else None
+            r = e.run_steps(step, nb, 0.05, u_pick[step - 3:], u_def[step - 3:], u_np[pos:], rng_mode=1, seed=11,
+                            thermal_mode=thermal_mode, q_planes=q, incremental=bool(la))
+            assert r["done"] == nb
+            pos += r["np_used"]
+            step += nb
+            res.append((r["totals"].tobytes(), r["events"].tobytes()))
+        rb = e.run_supersteps(step, 45, 8, 0.02, seed=3, thermal_mode=thermal_mode,
+                              q_planes=synthetic.laser_planes(L, step, 45) if thermal_mode == 2 else None)
+        d = e.download_planes(0, L, state=True, theta=True, phi=True, T=True, defects=True)
+        outs.append((res, rb["totals"].tobytes(), rb["n_exec"].tobytes(), {k: v.tobytes() for k, v in d.items()}, e.rate_sweep()))
+        e.close()
+    assert outs[0] == outs[1]
