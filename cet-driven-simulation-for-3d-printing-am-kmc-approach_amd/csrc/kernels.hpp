@@ -208,7 +208,10 @@ __global__ __launch_bounds__(256) void k_sweep_simple(KParams P, SlabView S, con
 // tree in the lane, DPP / v_permlane*_swap butterfly, chunk tree; event counts are scalar popcounts of ballots.
 // HW: rows of <= 256 voxels occupy half a wave, a wave then carries two rows.
 // ----------------------------------------------------------------------------------------
-constexpr int STREAM_NI = 8;      // planes per block
+#ifndef CETKMC_STREAM_NI
+#define CETKMC_STREAM_NI 8
+#endif
+constexpr int STREAM_NI = CETKMC_STREAM_NI;      // planes per block (A/B builds: -DCETKMC_STREAM_NI=16)
 constexpr int STREAM_SLOTS = 6;   // ring slots
 constexpr int STREAM_MAXPF = 3;   // 16-B chunks of a class slab per thread (L <= 682: 12 rows x 704 B = 528 chunks)
 
