@@ -718,13 +718,31 @@ __device__ __forceinline__ void heap_build(double* hs, int* hf, int P, int tid)
     __syncthreads();
 }
 // go left iff the right half holds no events, or the left holds events and base+sum(left) >= r
+// Two tree levels per LDS round trip: the children's and both grandchild pairs' entries are requested together, then the two
+// decisions are taken from registers (same comparisons, same order of additions as the one-level loop).
 __device__ __forceinline__ int heap_descend(const double* hs, const int* hf, int P, double& base, double r)
 {
     int n = 1;
     while (n < P) {
-        int l = 2 * n;
-        if (hf[l + 1] == 0 || (hf[l] != 0 && base + hs[l] >= r)) n = l;
-        else { base += hs[l]; n = l + 1; }
+        const int l = 2 * n;
+        const double sl = hs[l];
+        const int fl = hf[l], fr = hf[l + 1];
+        if (l < P) {
+            const int ll = 2 * l, rl = 2 * l + 2;
+            const double sll = hs[ll], srl = hs[rl];
+            const int fll = hf[ll], flr = hf[ll + 1], frl = hf[rl], frr = hf[rl + 1];
+            if (fr == 0 || (fl != 0 && base + sl >= r)) {
+                if (flr == 0 || (fll != 0 && base + sll >= r)) n = ll;
+                else { base += sll; n = ll + 1; }
+            } else {
+                base += sl;
+                if (frr == 0 || (frl != 0 && base + srl >= r)) n = rl;
+                else { base += srl; n = rl + 1; }
+            }
+        } else {
+            if (fr == 0 || (fl != 0 && base + sl >= r)) n = l;
+            else { base += sl; n = l + 1; }
+        }
     }
     return n - P;
 }
@@ -742,6 +760,7 @@ __device__ long long g_sel_stamps[16];
 // and the step's uniforms, requested behind the selection's own loads instead of in a chain of their own.
 struct SelCarry {
     double total, u_def, u_th, u_ph;
+    double ov[3];          // orientation unit vector of (pi u_th, 2 pi u_ph): computed by an idle wave during the selection
     long long n_events, n_dep, np_pos, cur;
     int ready;
 };
@@ -846,6 +865,10 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
     __syncthreads();
     SEL_STAMP(3);
     if (!sh_go) return;
+    // a deposition / nucleation will write the orientation (pi u_th, 2 pi u_ph) (kmc_simulation.py:283-284,308-309): its unit
+    // vector (two sincos) is worked out now by a thread of the otherwise idle second wave, same expressions as the application
+    if (carry && tid == 64)
+        orient_vec(0.0 + (3.141592653589793 - 0.0) * carry->u_th, 0.0 + (6.283185307179586 - 0.0) * carry->u_ph, carry->ov);
     const SlabView S = (sh_slab == 0) ? S0 : slabs[sh_slab];
     const int b = sh_b, i = b / 3, c = b - 3 * i;
     const int lp = i - S.gi0, li = lp + 2;
@@ -1247,7 +1270,8 @@ __global__ __launch_bounds__(256) void k_interface_part(KParams P, SlabView S, c
 }
 
 // ---- apply -------------------------------------------------------------------------------
-__device__ __forceinline__ void write_site(const SlabView& S, int i, int j, int k, int st, double th, double ph)
+// ov: the unit vector of (th, ph) if the caller already holds it (same orient_vec() bits), else null
+__device__ __forceinline__ void write_site(const SlabView& S, int i, int j, int k, int st, double th, double ph, const double* ov = nullptr)
 {
     const int li = i - (S.gi0 - 2);
     if (li < 0 || li >= S.nloc + 4) return;
@@ -1256,16 +1280,20 @@ __device__ __forceinline__ void write_site(const SlabView& S, int i, int j, int 
     S.cls[S.cidx(li, j, k)] = class8(st);
     const int64_t q = S.tidx(li, j, k);
     S.theta[q] = th; S.phi[q] = ph;
-    orient_vec(th, ph, S.ovec + 3 * q);
+    double* o = S.ovec + 3 * q;
+    if (ov) { o[0] = ov[0]; o[1] = ov[1]; o[2] = ov[2]; }
+    else if (__double_as_longlong(th) == 0 && __double_as_longlong(ph) == 0) { o[0] = 0.0; o[1] = 0.0; o[2] = 1.0; }   // sin 0 = 0, cos 0 = 1
+    else orient_vec(th, ph, o);
 }
 // kmc_simulation.py:276-327 on every local slab whose extended range holds the voxel(s)
-__device__ __forceinline__ void apply_event(const SlabView* slabs, int nslabs, const cetkmc_event& ev, int make_defect)
+// ov: unit vector of (ev.theta, ev.phi) if already known (the fused selection computes it for dep / nuc events)
+__device__ __forceinline__ void apply_event(const SlabView* slabs, int nslabs, const cetkmc_event& ev, int make_defect, const double* ov = nullptr)
 {
     for (int s = 0; s < nslabs; ++s) {
         const SlabView& S = slabs[s];
         int ui = ev.pos[0], uj = ev.pos[1], uk = ev.pos[2];
         if (ev.type == EV_DEP || ev.type == EV_NUC || ev.type == EV_ATT) {
-            write_site(S, ui, uj, uk, ev.atom, ev.theta, ev.phi);
+            write_site(S, ui, uj, uk, ev.atom, ev.theta, ev.phi, ov);
         } else if (ev.type == EV_DIFF) {
             write_site(S, ev.target[0], ev.target[1], ev.target[2], ev.atom, ev.theta, ev.phi);
             write_site(S, ui, uj, uk, 0, 0.0, 0.0);
@@ -1405,7 +1433,7 @@ __device__ __forceinline__ void apply_batch_body(const KParams& P, const SlabVie
                     if (ev.type == EV_NUC) ss->nuc_count += 1;
                 }
                 const int mk = (cfg.defect_fraction > 0.0 && (have ? carry->u_def : u_defect[s]) < cfg.defect_fraction) ? 1 : 0;
-                apply_event(slabs, nslabs, ev, mk);
+                apply_event(slabs, nslabs, ev, mk, (have && (ev.type == EV_DEP || ev.type == EV_NUC)) ? carry->ov : nullptr);
                 ss->np_pos = pos;
                 if (log_total) log_total[s] = have ? carry->total : ss->total;
                 if (log_event) log_event[s] = ev;
