@@ -675,78 +675,6 @@ __global__ __launch_bounds__(64) void k_plane_reduce(SlabView S, BlockEnt* __res
     plane_reduce_wave<false>(S.rowsum, S.rowcnt, blocks, S.L, S.Pk, S.gi0, b / 3, b % 3, (int)threadIdx.x);
 }
 
-// ---- LDS heap tree helpers (leaves at [P,2P), node n has children 2n, 2n+1) -------------
-// Built with two barriers instead of log2(P): every thread folds its P/256 consecutive leaves, the next six levels
-// are wave shuffles (a + b and b + a are the same double, so both lanes of a pair hold the node's value), thread 0
-// finishes the top two.  Same pairwise association as the level-by-level loop.  Callers sync before (leaves written).
-__device__ __forceinline__ void heap_build(double* hs, int* hf, int P, int tid)
-{
-    if (P < 256) {
-        for (int n = P >> 1; n >= 1; n >>= 1) {
-            for (int idx = tid; idx < n; idx += 256) {
-                int node = n + idx;
-                hs[node] = hs[2 * node] + hs[2 * node + 1];
-                hf[node] = hf[2 * node] | hf[2 * node + 1];
-            }
-            __syncthreads();
-        }
-        return;
-    }
-    for (int w = P >> 9, base = P >> 1; w >= 1; w >>= 1, base >>= 1)      // levels inside the thread's own leaves
-        for (int q = 0; q < w; ++q) {
-            const int node = base + w * tid + q;
-            hs[node] = hs[2 * node] + hs[2 * node + 1];
-            hf[node] = hf[2 * node] | hf[2 * node + 1];
-        }
-    double v = hs[256 + tid];
-    int f = hf[256 + tid];
-#pragma unroll
-    for (int l = 0; l < 6; ++l) {
-        v = v + __shfl_xor(v, 1 << l);
-        f |= __shfl_xor(f, 1 << l);
-        if ((tid & ((2 << l) - 1)) == 0) {
-            const int node = (256 >> (l + 1)) + (tid >> (l + 1));
-            hs[node] = v; hf[node] = f;
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        hs[2] = hs[4] + hs[5]; hf[2] = hf[4] | hf[5];
-        hs[3] = hs[6] + hs[7]; hf[3] = hf[6] | hf[7];
-        hs[1] = hs[2] + hs[3]; hf[1] = hf[2] | hf[3];
-    }
-    __syncthreads();
-}
-// go left iff the right half holds no events, or the left holds events and base+sum(left) >= r
-// Two tree levels per LDS round trip: the children's and both grandchild pairs' entries are requested together, then the two
-// decisions are taken from registers (same comparisons, same order of additions as the one-level loop).
-__device__ __forceinline__ int heap_descend(const double* hs, const int* hf, int P, double& base, double r)
-{
-    int n = 1;
-    while (n < P) {
-        const int l = 2 * n;
-        const double sl = hs[l];
-        const int fl = hf[l], fr = hf[l + 1];
-        if (l < P) {
-            const int ll = 2 * l, rl = 2 * l + 2;
-            const double sll = hs[ll], srl = hs[rl];
-            const int fll = hf[ll], flr = hf[ll + 1], frl = hf[rl], frr = hf[rl + 1];
-            if (fr == 0 || (fl != 0 && base + sl >= r)) {
-                if (flr == 0 || (fll != 0 && base + sll >= r)) n = ll;
-                else { base += sll; n = ll + 1; }
-            } else {
-                base += sl;
-                if (frr == 0 || (frl != 0 && base + srl >= r)) n = rl;
-                else { base += srl; n = rl + 1; }
-            }
-        } else {
-            if (fr == 0 || (fl != 0 && base + sl >= r)) n = l;
-            else { base += sl; n = l + 1; }
-        }
-    }
-    return n - P;
-}
-
 // A/B instrumentation (tools/sel_stamps.py, alternative build with -DCETKMC_SEL_STAMPS): thread 0 records the 100 MHz
 // wall clock at the phase boundaries of the fused selection + application kernel
 #ifdef CETKMC_SEL_STAMPS
@@ -761,9 +689,108 @@ __device__ long long g_sel_stamps[16];
 struct SelCarry {
     double total, u_def, u_th, u_ph;
     double ov[3];          // orientation unit vector of (pi u_th, 2 pi u_ph): computed by an idle wave during the selection
-    long long n_events, n_dep, np_pos, cur;
+    long long n_events, n_dep, np_pos, cur, nuc_count;
     int ready;
 };
+
+// ---- the selection trees, in registers ------------------------------------------------------------------------------
+// One canonical tree (leaves = 256 * npt, npt = 1, 2, 4 or 8 consecutive leaves per thread; a shorter tree is padded with
+// empty leaves, which changes neither a sum nor a descent) built and descended without an LDS heap: the thread's own
+// leaves fold in registers, the six levels of a wave by DPP / v_permlane*_swap with EVERY level's block sum kept (a lane
+// holds the sum of each aligned block it belongs to), the four wave sums meet in LDS (barrier 1).  Every thread then walks
+// the two top levels; the chosen wave continues with v_readlane of the kept block sums (scalar work, no memory) down to a
+// lane, every lane descends its own leaves, the chosen lane's answer is published (barrier 2).  "Holds events" flags are
+// ballot bits.  Descent rule: go left iff the right half holds no events, or the left holds events and base + sum(left) >= r
+// (DESIGN.md section 3); pairs and order of additions are those of the balanced tree over the leaf index.
+struct TreeScratch { double ws[4]; unsigned long long wm[4]; double base; int leaf; };
+struct TreeSel { int leaf; double base, total; };
+__device__ __forceinline__ double readlane_f64(double v, int lane_uniform)
+{
+    const int l = __builtin_amdgcn_readfirstlane(lane_uniform);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+template <class RFN>
+__device__ __forceinline__ TreeSel tree_select(const double (&lf)[8], unsigned fm, int npt, double base0, RFN rfn, TreeScratch& X, int tid)
+{
+    const int lane = tid & 63, w = tid >> 6;
+    // the thread's 8 leaf slots (npt used, the rest empty)
+    const double p0 = lf[0] + lf[1], p1 = lf[2] + lf[3], p2 = lf[4] + lf[5], p3 = lf[6] + lf[7];
+    const double q0 = p0 + p1, q1 = p2 + p3;
+    double lv[7];
+    lv[0] = q0 + q1;
+    lv[1] = lv[0] + dpp_f64(lv[0], 0);
+    lv[2] = lv[1] + dpp_f64(lv[1], 1);
+    lv[3] = lv[2] + dpp_f64(lv[2], 2);
+    lv[4] = lv[3] + dpp_f64(lv[3], 3);
+    {
+        const unsigned lo = __double2loint(lv[4]), hi = __double2hiint(lv[4]);
+        const auto r0 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto r1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        lv[5] = __hiloint2double((int)r1[0], (int)r0[0]) + __hiloint2double((int)r1[1], (int)r0[1]);
+    }
+    {
+        const unsigned lo = __double2loint(lv[5]), hi = __double2hiint(lv[5]);
+        const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        lv[6] = __hiloint2double((int)r1[0], (int)r0[0]) + __hiloint2double((int)r1[1], (int)r0[1]);
+    }
+    const unsigned long long mask = __ballot(fm != 0u);
+    if (lane == 0) { X.ws[w] = lv[6]; X.wm[w] = mask; }
+    __syncthreads();
+    const double w0 = X.ws[0], w1 = X.ws[1], w2 = X.ws[2], w3 = X.ws[3];
+    const unsigned long long m0 = X.wm[0], m1 = X.wm[1], m2 = X.wm[2], m3 = X.wm[3];
+    const double h0 = w0 + w1, h1 = w2 + w3;
+    TreeSel out;
+    out.total = h0 + h1;
+    const double r = rfn(out.total);
+    double base = base0;
+    int wsel;
+    {   // go left iff the right half holds no events, or the left holds events and base + sum(left) >= r
+        int half;
+        if ((m2 | m3) == 0ull || ((m0 | m1) != 0ull && base + h0 >= r)) half = 0;
+        else { base += h0; half = 1; }
+        const double sl = half ? w2 : w0;
+        const unsigned long long ml = half ? m2 : m0, mr = half ? m3 : m1;
+        if (mr == 0ull || (ml != 0ull && base + sl >= r)) wsel = 2 * half;
+        else { base += sl; wsel = 2 * half + 1; }
+    }
+    if (w == wsel) {
+        int a = 0;
+#pragma unroll
+        for (int l = 5; l >= 0; --l) {
+            const int hw = 1 << l;
+            const double sl = readlane_f64(lv[l], a);
+            const unsigned long long bits = (hw == 32) ? 0xFFFFFFFFull : ((1ull << hw) - 1ull);
+            const bool fl = ((mask >> a) & bits) != 0ull, fr = ((mask >> (a + hw)) & bits) != 0ull;
+            if (!(!fr || (fl && base + sl >= r))) { base += sl; a += hw; }
+        }
+        // inside the lane: every lane walks its own 8 slots from the same base; the chosen lane's walk counts
+        double bl = base;
+        int slot;
+        {
+            const bool fq0 = (fm & 0x0Fu) != 0u, fq1 = (fm & 0xF0u) != 0u;
+            int hq;
+            if (!fq1 || (fq0 && bl + q0 >= r)) hq = 0; else { bl += q0; hq = 1; }
+            const double pl = hq ? p2 : p0;
+            const unsigned f4 = (fm >> (4 * hq)) & 0xFu;
+            int hp;
+            if ((f4 & 0xCu) == 0u || ((f4 & 0x3u) != 0u && bl + pl >= r)) hp = 0; else { bl += pl; hp = 1; }
+            const int s2 = 4 * hq + 2 * hp;
+            const double ll = (s2 == 0) ? lf[0] : (s2 == 2) ? lf[2] : (s2 == 4) ? lf[4] : lf[6];
+            const unsigned f2 = (fm >> s2) & 0x3u;
+            int hl;
+            if ((f2 & 0x2u) == 0u || ((f2 & 0x1u) != 0u && bl + ll >= r)) hl = 0; else { bl += ll; hl = 1; }
+            slot = s2 + hl;
+        }
+        const int la = __builtin_amdgcn_readfirstlane(a);
+        const int slot_a = __builtin_amdgcn_readlane(slot, la);
+        const double base_a = readlane_f64(bl, la);
+        if (lane == 0) { X.leaf = (wsel * 64 + la) * npt + slot_a; X.base = base_a; }
+    }
+    __syncthreads();
+    out.leaf = X.leaf; out.base = X.base;
+    return out;
+}
 
 // k_select: single block.  (1) total + termination checks, (2) block descent, (3) row descent
 // in the owning slab, (4) voxel descent (leaves looked up in the rate table), (5) slot scan.
@@ -775,26 +802,26 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
                                             long long cur_hint = -1, SelCarry* carry = nullptr,
                                             const double* __restrict__ u_defect = nullptr, const double* __restrict__ u_np = nullptr)
 {
-    __shared__ double hs[2 * PMAX];
-    __shared__ int hf[2 * PMAX];
-    __shared__ int leafcnt[PMAX];
+    __shared__ double leafval[PMAX];           // the voxel tree's leaves (the chosen one is read back)
+    __shared__ int rowcnt_l[PMAX], voxcnt_l[PMAX];     // event counts of the chosen block's rows / the chosen row's voxels (deposition rank)
     __shared__ double ktab[225];
-    __shared__ long long red[256];
-    __shared__ double sh_base, sh_r;
-    __shared__ int sh_go, sh_b, sh_slab, sh_j, sh_k;
+    __shared__ long long red[4];
+    __shared__ TreeScratch X;
+    __shared__ double sh_u0, sh_base, sh_r;
+    __shared__ int sh_go, sh_b, sh_slab;
     __shared__ int sh_gi0[64], sh_nloc[64];
     __shared__ long long sh_ndep;
     const int tid = threadIdx.x;
     SEL_STAMP(0);
-    // everything thread 0 will need after the first heap is requested now, behind the block loads: the batch status, the
-    // step's uniforms, the stream cursor and the slabs' plane ranges; the first slab's view (the only one in most runs)
-    // comes with them
+    // everything thread 0 will need is requested now, behind the block loads: the batch status, the step's uniforms, the
+    // stream cursor and the slabs' plane ranges; the first slab's view (the only one in most runs) comes with them
     double u0 = 0.0, u_def = 0.0, u_th = 0.0, u_ph = 0.0;
-    long long np_pos0 = 0, cur = 0;
+    long long np_pos0 = 0, cur = 0, nuc0 = 0;
     int status0 = 0;
     if (tid == 0 && cfg.batch) {
         status0 = ss->status;
         np_pos0 = ss->np_pos;
+        nuc0 = ss->nuc_count;
         cur = cur_hint >= 0 ? cur_hint : ss->cur;
         u0 = u_pick[cur];
         if (carry && u_defect && cfg.defect_fraction > 0.0) u_def = u_defect[cur];
@@ -804,26 +831,34 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
     const SlabView S0 = slabs[0];
     if (tid < nslabs && tid < 64) { sh_gi0[tid] = slabs[tid].gi0; sh_nloc[tid] = slabs[tid].nloc; }
     const int NBk = 3 * L;
+    // ---- (1)+(2) blocks: thread t owns blocks [t*npb, (t+1)*npb)
+    const int npb = PB >= 256 ? (PB >> 8) : 1;
+    double lf[8];
+    unsigned fm = 0u;
     long long csum = 0;
-    for (int idx = tid; idx < PB; idx += 256) {
-        double v = 0.0; int f = 0;
-        if (idx < NBk) {
-            v = blocks[idx].sum; long long c = blocks[idx].cnt; f = c > 0; csum += c;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        lf[u] = 0.0;
+        const int idx = tid * npb + u;
+        if (u < npb && idx < NBk) {
+            lf[u] = blocks[idx].sum;
+            const long long c = blocks[idx].cnt;
+            csum += c;
+            if (c > 0) fm |= 1u << u;
             if (idx == 3 * (L - 1) + CAT_DEP) sh_ndep = c;
         }
-        hs[PB + idx] = v; hf[PB + idx] = f;
     }
     if (tid < 225) ktab[tid] = ktab_g[tid];
 #pragma unroll
     for (int l = 0; l < 6; ++l) csum += __shfl_xor(csum, 1 << l);       // per-wave event count
     if ((tid & 63) == 0) red[tid >> 6] = csum;
-    __syncthreads();
+    if (tid == 0) sh_u0 = u0;
     SEL_STAMP(1);
-    heap_build(hs, hf, PB, tid);
+    const TreeSel ta = tree_select(lf, fm, npb, 0.0, [&](double total) { return cfg.batch ? sh_u0 * total : r_direct; }, X, tid);
     SEL_STAMP(2);
     if (tid == 0 && status0) sh_go = 0;                 // terminated / exhausted batch: nothing is read or written
     else if (tid == 0) {
-        const double total = hs[1];
+        const double total = ta.total;
         const long long n_events = red[0] + red[1] + red[2] + red[3];
         const long long n_dep = sh_ndep;
         ss->total = total; ss->n_events = n_events; ss->n_dep = n_dep;
@@ -842,21 +877,20 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
         }
         if (go) {
             const double r = cfg.batch ? u0 * total : r_direct;
-            double base = 0.0;
-            const int b = heap_descend(hs, hf, PB, base, r);
+            const int b = ta.leaf;
             const int i = b / 3;
             int sl = -1;
             for (int s = 0; s < nslabs; ++s) {
                 const int g0 = s < 64 ? sh_gi0[s] : slabs[s].gi0, nl = s < 64 ? sh_nloc[s] : slabs[s].nloc;
                 if (i >= g0 && i < g0 + nl) sl = s;
             }
-            sh_b = b; sh_slab = sl; sh_base = base; sh_r = r;
+            sh_b = b; sh_slab = sl; sh_base = ta.base; sh_r = r;
             if (sl < 0) go = 0;     // owned by another rank
             if (go && carry) {
                 // reference stream: the orientation draws follow this sweep's n_dep species draws
                 if (u_np && cfg.rng_mode == 0) { u_th = u_np[np_pos0 + n_dep]; u_ph = u_np[np_pos0 + n_dep + 1]; }
                 carry->total = total; carry->n_events = n_events; carry->n_dep = n_dep; carry->np_pos = np_pos0; carry->cur = cur;
-                carry->u_def = u_def; carry->u_th = u_th; carry->u_ph = u_ph;
+                carry->u_def = u_def; carry->u_th = u_th; carry->u_ph = u_ph; carry->nuc_count = nuc0;
                 carry->ready = 1;
             }
         }
@@ -874,78 +908,87 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
     const int lp = i - S.gi0, li = lp + 2;
     const double r = sh_r;
     const int Pk = S.Pk;
-    // rows
-    for (int idx = tid; idx < Pk; idx += 256) {
-        double v = 0.0; int cv = 0;
-        if (idx < L) { v = S.rowsum[((int64_t)lp * 3 + c) * L + idx]; cv = S.rowcnt[((int64_t)lp * 3 + c) * L + idx]; }
-        hs[Pk + idx] = v; hf[Pk + idx] = cv > 0; leafcnt[idx] = cv;
+    const int npk = Pk >= 256 ? (Pk >> 8) : 1;
+    // ---- (3) rows of block (i, c): thread t owns rows [t*npk, (t+1)*npk)
+    fm = 0u;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        lf[u] = 0.0;
+        const int idx = tid * npk + u;
+        if (u < npk && idx < Pk) {
+            int cv = 0;
+            if (idx < L) { lf[u] = S.rowsum[((int64_t)lp * 3 + c) * L + idx]; cv = S.rowcnt[((int64_t)lp * 3 + c) * L + idx]; }
+            if (cv > 0) fm |= 1u << u;
+            rowcnt_l[idx] = cv;
+        }
     }
-    __syncthreads();
     SEL_STAMP(4);
-    heap_build(hs, hf, Pk, tid);
-    if (tid == 0) {
-        double base = sh_base;
-        const int j = heap_descend(hs, hf, Pk, base, r);
-        long long rank = 0;
-        if (c == CAT_DEP) for (int jj = 0; jj < j; ++jj) rank += leafcnt[jj];
-        red[0] = rank;
-        sh_j = j; sh_base = base;
-    }
-    __syncthreads();
+    const TreeSel tb = tree_select(lf, fm, npk, sh_base, [&](double) { return r; }, X, tid);
+    const int j = tb.leaf;
     SEL_STAMP(5);
-    const int j = sh_j;
-    // voxels of row (i, c, j).  With the rate table (ifc_ready): a leaf is a lookup -- listed voxels hold their full
+    // ---- (4) voxels of row (i, c, j).  With the rate table (ifc_ready): a leaf is a lookup -- listed voxels hold their full
     // EMPTY/DIFF category sum and count (k_interface / ifc_touch; every interface voxel is listed), every other empty
     // voxel its nucleation rate by temperature (k_rate_table), plane L-1 its deposition rates (dep_val).  Without it
     // (simple kernel): re-evaluated here.
-    for (int k = tid; k < Pk; k += 256) {
-        double sum = 0.0; int cnt = 0;
-        int maybe_ifc = 1;      // 0: certainly no interface voxel (its EMPTY category can only hold a nucleation)
-        if (k < L) {
-            // state, membership flag, table entry, count (and temperature) are requested together (one round trip)
-            const int64_t t = S.tidx(li, j, k);
-            const int st = S.state[S.sidx(li, j, k)];
-            const bool listed = ifc_ready && S.ifc_in[t] != 0;
-            maybe_ifc = (!ifc_ready || listed) ? 1 : 0;
-            const double v_tab = S.vval[t];
-            const int c_ifc = S.ifc_cnt[t];
-            if (ifc_ready) {
-                if (c == CAT_DEP) {
-                    const double rate = S.dep_val[(int64_t)j * S.pitchT + k];
-                    if (st == 0 && finite_d(rate)) { sum = rate; cnt = 1; }
-                } else if (listed) {
-                    if ((c == CAT_EMPTY) == (st == 0)) { sum = v_tab; cnt = c_ifc; }
-                } else if (c == CAT_EMPTY && st == 0) {
-                    sum = v_tab; cnt = (v_tab != 0.0) ? 1 : 0;
+    fm = 0u;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        lf[u] = 0.0;
+        const int k = tid * npk + u;
+        if (u < npk && k < Pk) {
+            double sum = 0.0; int cnt = 0;
+            int maybe_ifc = 1;      // 0: certainly no interface voxel (its EMPTY category can only hold a nucleation)
+            if (k < L) {
+                // state, membership flag, table entry, count (and temperature) are requested together (one round trip)
+                const int64_t t = S.tidx(li, j, k);
+                const int st = S.state[S.sidx(li, j, k)];
+                const bool listed = ifc_ready && S.ifc_in[t] != 0;
+                maybe_ifc = (!ifc_ready || listed) ? 1 : 0;
+                const double v_tab = S.vval[t];
+                const int c_ifc = S.ifc_cnt[t];
+                if (ifc_ready) {
+                    if (c == CAT_DEP) {
+                        const double rate = S.dep_val[(int64_t)j * S.pitchT + k];
+                        if (st == 0 && finite_d(rate)) { sum = rate; cnt = 1; }
+                    } else if (listed) {
+                        if ((c == CAT_EMPTY) == (st == 0)) { sum = v_tab; cnt = c_ifc; }
+                    } else if (c == CAT_EMPTY && st == 0) {
+                        sum = v_tab; cnt = (v_tab != 0.0) ? 1 : 0;
+                    }
+                } else {
+                    const double Traw = S.T[t];
+                    auto nb = [&](int mm) -> int { return S.state[S.sidx(li + nbi_rt(mm), j + nbj_rt(mm), k + nbk_rt(mm))]; };
+                    auto emit = [&](int cat, int, double rate, int, int) { if (cat == c) { sum += rate; ++cnt; } };
+                    eval_voxel(P, S, ktab, li, i, j, k, st, Traw, nb, emit);
                 }
-            } else {
-                const double Traw = S.T[t];
-                auto nb = [&](int mm) -> int { return S.state[S.sidx(li + nbi_rt(mm), j + nbj_rt(mm), k + nbk_rt(mm))]; };
-                auto emit = [&](int cat, int, double rate, int, int) { if (cat == c) { sum += rate; ++cnt; } };
-                eval_voxel(P, S, ktab, li, i, j, k, st, Traw, nb, emit);
             }
+            lf[u] = sum;
+            if (cnt > 0) fm |= 1u << u;
+            leafval[k] = sum;
+            voxcnt_l[k] = cnt | (maybe_ifc << 8);
         }
-        hs[Pk + k] = sum; hf[Pk + k] = cnt > 0; leafcnt[k] = cnt | (maybe_ifc << 8);
     }
-    __syncthreads();
     SEL_STAMP(6);
-    heap_build(hs, hf, Pk, tid);
+    const TreeSel tc = tree_select(lf, fm, npk, tb.base, [&](double) { return r; }, X, tid);
     SEL_STAMP(7);
     if (tid == 0) {
-        double base = sh_base;
-        const int k = heap_descend(hs, hf, Pk, base, r);
-        long long rank = red[0];
-        if (c == CAT_DEP) for (int kk = 0; kk < k; ++kk) rank += leafcnt[kk] & 255;
+        const int k = tc.leaf;
+        const double base = tc.base;
+        long long rank = 0;
+        if (c == CAT_DEP) {
+            for (int jj = 0; jj < j; ++jj) rank += rowcnt_l[jj];
+            for (int kk = 0; kk < k; ++kk) rank += voxcnt_l[kk] & 255;
+        }
         // slot scan (kmc_simulation.py:268-274 restricted to this voxel's slots)
         int p_type = -1, p_m = -1, p_atom = 0;
         double p_rate = 0.0;
-        const int lc = leafcnt[k];
+        const int lc = voxcnt_l[k];
         if ((lc & 255) == 1 && (c == CAT_DEP || (c == CAT_EMPTY && !(lc >> 8)))) {
             // a single event whose kind is known without looking again: the deposition of this voxel, or the nucleation
             // of an empty voxel without W/Re/C neighbours; its rate is the leaf itself
             p_type = (c == CAT_DEP) ? EV_DEP : EV_NUC;
             p_atom = (c == CAT_DEP) ? 0 : 1;
-            p_rate = hs[Pk + k];
+            p_rate = leafval[k];
         } else {
             const int st = S.state[S.sidx(li, j, k)];
             double cum = base;
@@ -1430,7 +1473,7 @@ __device__ __forceinline__ void apply_batch_body(const KParams& P, const SlabVie
                     ev.theta = 0.0 + (3.141592653589793 - 0.0) * ut;       // np.random.uniform(0, pi)
                     ev.phi = 0.0 + (6.283185307179586 - 0.0) * up;         // np.random.uniform(0, 2*pi)
                     pos += 2;
-                    if (ev.type == EV_NUC) ss->nuc_count += 1;
+                    if (ev.type == EV_NUC) { if (have) ss->nuc_count = carry->nuc_count + 1; else ss->nuc_count += 1; }
                 }
                 const int mk = (cfg.defect_fraction > 0.0 && (have ? carry->u_def : u_defect[s]) < cfg.defect_fraction) ? 1 : 0;
                 apply_event(slabs, nslabs, ev, mk, (have && (ev.type == EV_DEP || ev.type == EV_NUC)) ? carry->ov : nullptr);
