@@ -1000,6 +1000,12 @@ int cetkmc_set_option(void* handle, const char* key, int64_t value)
         return 0;
     }
     if (!strcmp(key, "thermal_lookahead")) { h->thermal_ahead = value ? 1 : 0; return 0; }
+    if (!strcmp(key, "reserve_profile_events")) {      // hipEvents of a profiled batch of `value` steps, created ahead of it
+        if (value < 0 || value > (1 << 20)) return fail("reserve_profile_events out of range");
+        HIPCHK(hipSetDevice(h->dev));
+        while ((int64_t)h->prof.size() < 7 * value) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->prof.push_back(e); }
+        return 0;
+    }
     if (!strcmp(key, "thermal_variant")) {
         if (value < 0 || value > 1) return fail("thermal_variant must be 0 (simple) or 1 (marching, default)");
         h->thermal_variant = (int)value;
