@@ -264,7 +264,7 @@ def main():
     timed_inputs = prepare(step, a.steps)
     # short runs (the driver's 20 steps): hipEvents around EVERY sweep launch; long runs: every 8th (a record costs ~5 us)
     prof_mode = 1 if a.steps <= 64 else 3
-    eng.set_option("reserve_profile_events", a.steps)          # their creation (~10 us each) stays out of the timed region
+    eng.set_option("reserve_batch", a.steps)       # batch buffers / hipEvents: hipMalloc and hipEventCreate stay out of the timed region
     barrier()
     t0 = time.perf_counter()
     r = run(step, a.steps, profile=prof_mode, prep=timed_inputs)
@@ -274,14 +274,28 @@ def main():
     step += a.steps
 
     # ---- after the timed region: per-phase device time (hipEvents at every phase boundary, cetkmc_get_counters)
-    phases = None
-    if not a.no_phases and (N == 1 or a.extras_multi):
+    extras_errors = {}
+
+    def guarded(name, fn):
+        """The extras run AFTER the timed region; one of them failing (e.g. a transport error at N > 1) must not cost the
+        headline line.  A failure is recorded in the JSON line, never hidden."""
+        try:
+            return fn()
+        except Exception as exc:                     # noqa: BLE001
+            extras_errors[name] = f"{type(exc).__name__}: {exc}"
+            print(f"bench extra '{name}' failed: {exc}", file=sys.stderr)
+            return None
+
+    st = {"step": step}          # the extras advance the trajectory one after another
+
+    def do_phases():
         n_ph = min(200, a.steps)
-        ph_inputs = prepare(step, n_ph)
+        ph_inputs = prepare(st["step"], n_ph)
         eng.counters(reset=True)
-        rp = run(step, n_ph, profile=2, prep=ph_inputs)
+        rp = run(st["step"], n_ph, profile=2, prep=ph_inputs)
         c = eng.counters()
-        step += rp["done"]
+        st["step"] += rp["done"]
+        phases = None
         if rp["done"] == n_ph and c["profiled_steps"] == n_ph:
             phases = {k[3:] + "_us_per_step": 1e3 * c[k] / n_ph for k in ("ms_thermal", "ms_interface", "ms_sweep", "ms_reduce",
                                                                            "ms_select_apply")}
@@ -292,20 +306,25 @@ def main():
                           alg_bytes_per_step=(c["alg_bytes_sweep"] + c["alg_bytes_thermal"] + c["alg_bytes_table"]) / n_ph,
                           note="full-sweep loop, hipEvents at every phase boundary (slower than the timed run by the event "
                                "records); thermal / rate table / interface list averaged over their 1-in-20 cadence")
+        return phases
+
+    phases = guarded("phases", do_phases) if (not a.no_phases and (N == 1 or a.extras_multi)) else None
 
     # ---- the recompute variant of the sweep kernel (nucleation rates evaluated in every sweep instead of looked up)
-    recompute = None
-    if not a.no_recompute and N == 1:
+    def do_recompute():
         n_rc = min(200, a.steps)
-        rc_inputs = prepare(step, n_rc)
+        rc_inputs = prepare(st["step"], n_rc)
         eng.set_option("sweep_variant", 2)
-        eng.sync()
-        t3 = time.perf_counter()
-        rr = run(step, n_rc, profile=1, prep=rc_inputs)
-        eng.sync()
-        dtr = time.perf_counter() - t3
-        eng.set_option("sweep_variant", 1)
-        step += rr["done"]
+        try:
+            eng.sync()
+            t3 = time.perf_counter()
+            rr = run(st["step"], n_rc, profile=1, prep=rc_inputs)
+            eng.sync()
+            dtr = time.perf_counter() - t3
+        finally:
+            eng.set_option("sweep_variant", 1)
+        st["step"] += rr["done"]
+        recompute = None
         if rr["done"] == n_rc and rr["sweep_launches"]:
             ms = rr["sweep_ms_total"] / rr["sweep_launches"]
             ach = B_ALG_SWEEP * (eng.i1 - eng.i0) * L * L / (ms * 1e-3) / 1e9
@@ -314,42 +333,56 @@ def main():
                          "note": "sweep_variant 2: streams T instead of the rate table and evaluates the nucleation rate of "
                                  "every bulk empty voxel in the sweep (same bits; tests/test_gpu_parity.py::"
                                  "test_sweep_variants_bit_identical); steps_per_s includes the hipEvent records"}
+        return recompute
+
+    recompute = guarded("sweep_recompute", do_recompute) if (not a.no_recompute and N == 1) else None
 
     # ---- the same loop in exact incremental mode (reported beside `value`, never as it)
-    inc = None
-    if not a.no_incremental and (N == 1 or a.extras_multi):
-        inc_inputs = prepare(step, a.steps)
+    def do_incremental():
+        inc_inputs = prepare(st["step"], a.steps)
         barrier()
         t1 = time.perf_counter()
-        ri = run(step, a.steps, prep=inc_inputs, incremental=True)
+        ri = run(st["step"], a.steps, prep=inc_inputs, incremental=True)
         barrier()
         dti = allreduce(time.perf_counter() - t1, "MAX")
-        step += ri["done"]
+        st["step"] += ri["done"]
+        inc = None
         if ri["done"] == a.steps:
             inc = {"steps_per_s": a.steps / dti, "ms_per_step": 1e3 * dti / a.steps, "full_sweeps": int(ri["full_sweeps"]),
                    "steps": a.steps,
                    "note": "cetkmc_run_steps incremental=1 on the following K steps: between temperature updates only the "
                            "rows the previous event made stale are re-evaluated; bit-identical to full sweeps "
                            "(tests/test_gpu_parity.py::test_incremental_mode_bit_identical); not part of `value`"}
+        return inc
+
+    inc = guarded("incremental_exact", do_incremental) if (not a.no_incremental and (N == 1 or a.extras_multi)) else None
 
     # ---- Mode B (super-steps over 8^3 boxes; not the reference's trajectory, own CPU comparator): executed events/s
-    mode_b = None
-    if not a.no_mode_b and L % 8 == 0 and (L // N) % 8 == 0:
-        nb_steps = 40
-        qb = synthetic.laser_planes(L, step, nb_steps)
+    def do_mode_b():
+        nb_steps, nb_warm = 40, 8
+        # untimed warm-up (first launch of the Mode B kernels loads their code objects: ~10 ms once per process)
+        rw = eng.run_supersteps(st["step"], nb_warm, 8, DEFECT_FRACTION, seed=SEED, thermal_mode=2,
+                                q_planes=synthetic.laser_planes(L, st["step"], nb_warm))
+        st["step"] += rw["done"]
+        qb = synthetic.laser_planes(L, st["step"], nb_steps)
         barrier()
         t2 = time.perf_counter()
-        rb = eng.run_supersteps(step, nb_steps, 8, DEFECT_FRACTION, seed=SEED, thermal_mode=2, q_planes=qb)
+        rb = eng.run_supersteps(st["step"], nb_steps, 8, DEFECT_FRACTION, seed=SEED, thermal_mode=2, q_planes=qb)
         barrier()
         dtb = allreduce(time.perf_counter() - t2, "MAX")
         n_exec = allreduce(float(rb["n_exec"].sum()), "SUM")          # every rank counts the events of its own boxes
+        mode_b = None
         if rb["done"] == nb_steps:
             mode_b = {"executed_events_per_s": n_exec / dtb, "ms_per_superstep": 1e3 * dtb / nb_steps,
                       "events_per_superstep": n_exec / nb_steps, "boxes": (L // 8) ** 3, "supersteps": nb_steps,
+                      "warmup_supersteps": nb_warm,
                       "note": "cetkmc_run_supersteps box=8 on the lattice left by the runs above: one full rate sweep per "
                               "super-step, every box executes <= 1 event from its active octant (boxes sharded with the "
                               "slabs; boundary-layer events exchanged with the neighbour ranks every super-step); "
                               "bit-identical to oracle orc_run_supersteps (tests/test_gpu_mode_b.py); not part of `value`"}
+        return mode_b
+
+    mode_b = guarded("mode_b", do_mode_b) if (not a.no_mode_b and L % 8 == 0 and (L // N) % 8 == 0) else None
 
     cand = float(np.sum(r["n_events"].astype(np.float64)))     # identical on every rank (global counts)
     steps_per_s = a.steps / dt
@@ -434,6 +467,8 @@ def main():
         out["incremental_exact"] = inc
     if mode_b is not None:
         out["mode_b"] = mode_b
+    if extras_errors:
+        out["extras_errors"] = extras_errors
     sys.stdout.flush()
     os.dup2(stdout_fd, 1)
     os.close(stdout_fd)

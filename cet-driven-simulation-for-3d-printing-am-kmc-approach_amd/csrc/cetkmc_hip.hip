@@ -1000,10 +1000,24 @@ int cetkmc_set_option(void* handle, const char* key, int64_t value)
         return 0;
     }
     if (!strcmp(key, "thermal_lookahead")) { h->thermal_ahead = value ? 1 : 0; return 0; }
-    if (!strcmp(key, "reserve_profile_events")) {      // hipEvents of a profiled batch of `value` steps, created ahead of it
-        if (value < 0 || value > (1 << 20)) return fail("reserve_profile_events out of range");
+    if (!strcmp(key, "reserve_batch")) {
+        // device buffers (uniform streams, per-step logs, one laser source plane per temperature update) and hipEvents of a
+        // batch of `value` steps, allocated ahead of it: a bench keeps hipMalloc / hipEventCreate out of its timed region
+        if (value < 0 || value > (1 << 22)) return fail("reserve_batch out of range");
         HIPCHK(hipSetDevice(h->dev));
-        while ((int64_t)h->prof.size() < 7 * value) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->prof.push_back(e); }
+        const size_t n = (size_t)value;
+        size_t c1 = h->cap_steps, c2 = h->cap_steps, c3 = h->cap_steps, c4 = h->cap_steps, c5 = h->cap_steps;
+        CHK(grow(&h->d_u_pick, &c1, n));
+        CHK(grow(&h->d_u_defect, &c2, n));
+        CHK(grow(&h->d_log_total, &c3, n));
+        CHK(grow(&h->d_log_event, &c4, n));
+        CHK(grow(&h->d_log_nev, &c5, n));
+        h->cap_steps = std::min({c1, c2, c3, c4, c5});
+        CHK(grow(&h->d_u_np, &h->cap_np, 2 * n + 2 + (size_t)h->L * h->L));
+        CHK(grow(&h->d_q, &h->cap_q, (n / 20 + 2) * (size_t)h->L * h->L));
+        // events: the per-phase mode (7 per step) is used on short batches only; the sampled modes need 2 per (8th) step
+        const int64_t need = std::max<int64_t>(7 * std::min<int64_t>(value, 256), value <= 64 ? 2 * value : 2 * (value / 8 + 1));
+        while ((int64_t)h->prof.size() < need) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->prof.push_back(e); }
         return 0;
     }
     if (!strcmp(key, "thermal_variant")) {
@@ -1258,13 +1272,9 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
     if (a->np_cap > 0) HIPCHK(hipMemcpyAsync(h->d_u_np, a->u_np, (size_t)a->np_cap * 8, hipMemcpyHostToDevice, h->stream));
     if (a->thermal_mode == 2 && n_therm > 0)
         HIPCHK(hipMemcpyAsync(h->d_q, a->q_planes, (size_t)n_therm * L2 * 8, hipMemcpyHostToDevice, h->stream));
-    // reset the batch part of the step state (nucleation_count persists)
+    // reset the batch part of the step state (nucleation_count persists): a one-thread kernel, no host round trip
     StepState ss;
-    HIPCHK(hipMemcpyAsync(&ss, h->d_ss, sizeof ss, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    ss.cur = 0; ss.status = 0; ss.np_pos = 0; ss.q_pos = 0;
-    HIPCHK(hipMemcpyAsync(h->d_ss, &ss, sizeof ss, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    hipLaunchKernelGGL(k_batch_reset, dim3(1), dim3(1), 0, h->stream, h->d_ss);
 
     BatchCfg cfg{};
     cfg.step0 = a->step0; cfg.np_cap = a->np_cap; cfg.defect_fraction = a->defect_fraction; cfg.seed = a->seed;
@@ -1276,7 +1286,8 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
     const int64_t pstride = a->profile == 3 ? 8 : 1;
     auto sampled = [&](int64_t s) { return a->profile == 1 || (a->profile == 3 && s % pstride == 0); };
     if (a->profile) {
-        while ((int64_t)h->prof.size() < EPS * n) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->prof.push_back(e); }
+        const int64_t need = a->profile == 2 ? EPS * n : 2 * ((n + pstride - 1) / pstride);     // sampled steps only
+        while ((int64_t)h->prof.size() < need) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->prof.push_back(e); }
     }
     auto pev = [&](int64_t s, int q) -> hipEvent_t { return a->profile == 2 ? h->prof[EPS * s + q] : nullptr; };
     std::vector<char> was_thermal, was_full;
@@ -1304,7 +1315,7 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
                 CHK(launch_select_apply(h, cfg, 1, h->d_dirty, s));
                 HIPCHK(hipEventRecord(pev(s, 5), h->stream));
             } else {
-                CHK(launch_dirty_rows(h, sampled(s) ? h->prof[2 * s] : nullptr, sampled(s) ? h->prof[2 * s + 1] : nullptr));
+                CHK(launch_dirty_rows(h, sampled(s) ? h->prof[2 * (s / pstride)] : nullptr, sampled(s) ? h->prof[2 * (s / pstride) + 1] : nullptr));
                 CHK(launch_select_apply(h, cfg, 1, h->d_dirty, s));
             }
             h->swept = false;
@@ -1321,7 +1332,7 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
             if (a->profile == 2) was_thermal[s] = 1;
         }
         if (a->profile == 2) CHK(launch_sweep(h, true, pev(s, 2), pev(s, 3), false, pev(s, 1), pev(s, 4)));
-        else if (sampled(s)) CHK(launch_sweep(h, true, h->prof[2 * s], h->prof[2 * s + 1]));
+        else if (sampled(s)) CHK(launch_sweep(h, true, h->prof[2 * (s / pstride)], h->prof[2 * (s / pstride) + 1]));
         else CHK(launch_sweep(h, true));
         CHK(launch_select_apply(h, cfg, (incr || eval_touched) ? 1 : 0, incr ? h->d_dirty : nullptr, s));
         if (!(incr || eval_touched)) h->ifc_fresh = false;
@@ -1330,7 +1341,15 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev1, h->stream));
+    // everything the host wants back travels behind ONE synchronisation: step state, the per-step logs (all n entries;
+    // only the first steps_done are meaningful) and the interface lists' lengths
     HIPCHK(hipMemcpyAsync(&ss, h->d_ss, sizeof ss, hipMemcpyDeviceToHost, h->stream));
+    if (totals && n > 0) HIPCHK(hipMemcpyAsync(totals, h->d_log_total, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+    if (events && n > 0) HIPCHK(hipMemcpyAsync(events, h->d_log_event, (size_t)n * sizeof(cetkmc_event), hipMemcpyDeviceToHost, h->stream));
+    if (n_events && n > 0) HIPCHK(hipMemcpyAsync(n_events, h->d_log_nev, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+    std::vector<int> list_len(h->slabs.size(), 0);
+    for (size_t sl = 0; sl < h->slabs.size(); ++sl)
+        HIPCHK(hipMemcpyAsync(&list_len[sl], h->slabs[sl].v.ifc_n, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (h->spec.valid) { HIPCHK(hipStreamSynchronize(h->stream2)); h->spec.valid = false; }      // never outlives its batch
     res->steps_done = ss.cur; res->status = ss.status; res->np_used = ss.np_pos; res->q_used = q_idx;
@@ -1368,7 +1387,7 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
         for (int64_t s = 0; s < n; ++s) {
             if (!sampled(s)) continue;
             float t = 0.f;
-            HIPCHK(hipEventElapsedTime(&t, h->prof[2 * s], h->prof[2 * s + 1]));
+            HIPCHK(hipEventElapsedTime(&t, h->prof[2 * (s / pstride)], h->prof[2 * (s / pstride) + 1]));
             res->sweep_ms_total += t;
             ++res->sweep_launches;
         }
@@ -1376,12 +1395,10 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
     h->cnt.steps += ss.cur;
     const int64_t done = ss.cur;
     const int64_t nt = done + (ss.status == 1 ? 1 : 0);
-    if (totals && done > 0) HIPCHK(hipMemcpy(totals, h->d_log_total, (size_t)done * 8, hipMemcpyDeviceToHost));
     if (totals && ss.status == 1 && nt <= n) totals[done] = ss.total;
-    if (events && done > 0) HIPCHK(hipMemcpy(events, h->d_log_event, (size_t)done * sizeof(cetkmc_event), hipMemcpyDeviceToHost));
-    if (n_events && done > 0) HIPCHK(hipMemcpy(n_events, h->d_log_nev, (size_t)done * 8, hipMemcpyDeviceToHost));
-    h->cnt.bytes_d2h += (totals ? done * 8 : 0) + (events ? done * (int64_t)sizeof(cetkmc_event) : 0) + (n_events ? done * 8 : 0);
-    CHK(refresh_ifc_grid(h));
+    h->cnt.bytes_d2h += (totals ? n * 8 : 0) + (events ? n * (int64_t)sizeof(cetkmc_event) : 0) + (n_events ? n * 8 : 0);
+    // the interface lists grow while stepping: keep the interface kernel's grid at one entry per thread
+    for (int n_list : list_len) h->ifc_blocks = std::max(h->ifc_blocks, std::min(8192, (n_list + 255) / 256 + 64));
     return 0;
 }
 

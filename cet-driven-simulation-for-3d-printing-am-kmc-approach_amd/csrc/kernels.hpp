@@ -1555,6 +1555,12 @@ __global__ __launch_bounds__(64) void k_apply_direct(KParams P, const SlabView* 
     apply_touch(P, slabs, nslabs, ktab_g, ev, threadIdx.x, 0, blockDim.x);
 }
 
+// start of a batch: the batch part of the step state (nucleation_count persists) -- on the stream, no host round trip
+__global__ void k_batch_reset(StepState* ss)
+{
+    ss->cur = 0; ss->status = 0; ss->np_pos = 0; ss->q_pos = 0;
+}
+
 // ---- thermal -------------------------------------------------------------------------------
 struct ThermalCfg {
     double dt, alpha, inv_dx2, clip_lo, clip_hi, T_nan, rho_cp, latent_coef;
