@@ -1204,6 +1204,7 @@ __device__ __forceinline__ void ifc_touch(const KParams& P, const SlabView& S, c
     const double Traw = eval ? S.T[t] : 0.0;
     bool hit;
     const unsigned code = ifc_encode(S, li, aj, ak, &hit);
+    SEL_STAMP(12);
     bool want = false;
     unsigned long long m = 0ull;
     int base = 0, leader = 0;
@@ -1219,6 +1220,7 @@ __device__ __forceinline__ void ifc_touch(const KParams& P, const SlabView& S, c
         }
     }
     if (listed) S.ifc_code[t] = code;
+    SEL_STAMP(13);
     if (eval && listed) {            // the same evaluation from the packed word as k_interface
         const int st = code_state(code);
         const double Tc = pymax(Traw, 1.0);
@@ -1230,6 +1232,7 @@ __device__ __forceinline__ void ifc_touch(const KParams& P, const SlabView& S, c
             ifc_store(S, li, aj, ak, t, sum, cnt, code);
         }
     }
+    SEL_STAMP(14);
     if (m) {
         base = __shfl(base, leader);
         if (want) S.ifc_list[base + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned)lp << 20) | ((unsigned)aj << 10) | (unsigned)ak;

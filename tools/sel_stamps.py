@@ -21,8 +21,9 @@ e.upload_planes(0, L, st, th, ph, T, df)
 e.set_prev_state(None)
 lib = _lib.load()
 names = ["start", "blocks loaded", "block heap", "block descent", "rows loaded", "row heap+descent", "voxels loaded",
-         "voxel heap", "descent+slot+record", "apply start", "writes done", "touch done"]
-acc = np.zeros(12)
+         "voxel heap", "descent+slot+record", "apply start", "writes done", "touch done",
+         "  touch: neighbourhood words", "  touch: flags / append issued", "  touch: evaluated + stored"]
+acc = np.zeros(15)
 rs = np.random.RandomState(1)
 n_samples = 0
 step = 0
@@ -34,10 +35,12 @@ for rep in range(60):
     step += r["done"]
     out = (C.c_longlong * 16)()
     assert lib.cetkmc_debug_sel_stamps(out) == 0
-    v = np.array(out[:12], dtype=np.float64)
+    v = np.array(out[:15], dtype=np.float64)
     if rep >= 5:
         acc += (v - v[0]) / 100.0      # us
         n_samples += 1
 acc /= n_samples
-for a, b, nm in zip(acc, np.diff(np.concatenate([[0.0], acc])), names):
+for a, b, nm in zip(acc[:12], np.diff(np.concatenate([[0.0], acc[:12]])), names[:12]):
     print(f"{nm:24s} t = {a:7.2f} us   (+{b:5.2f})")
+for a, nm in zip(acc[12:], names[12:]):
+    print(f"{nm:34s} t = {a:7.2f} us")
