@@ -384,17 +384,23 @@ def main():
 
     mode_b = guarded("mode_b", do_mode_b) if (not a.no_mode_b and L % 8 == 0 and (L // N) % 8 == 0) else None
 
+    ev_over_ms = guarded("event_overhead", lambda: eng.event_overhead(50))
     cand = float(np.sum(r["n_events"].astype(np.float64)))     # identical on every rank (global counts)
     steps_per_s = a.steps / dt
     sweep_ms = r["sweep_ms_total"] / max(r["sweep_launches"], 1)
     n_own = (eng.i1 - eng.i0) * L * L
     achieved = B_ALG_SWEEP * n_own / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
-    traffic, traffic_src = None, None
-    for summary_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")), reverse=True):
+    # from the committed rocprofv3 summary of the same command (profiles/rNN_summary.json, latest round): the kernel's own
+    # average duration in the kernel trace and the PMC traffic per launch -- not measured in this run
+    traffic, traffic_src, rocprof_ms = None, None, None
+    import re
+    rounds = [(int(m.group(1)), f) for f in glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json"))
+              for m in [re.fullmatch(r"r(\d+)_summary\.json", os.path.basename(f))] if m]
+    for _, summary_path in sorted(rounds, reverse=True):
         try:
             kk = json.load(open(summary_path))["kernels"]["k_sweep_stream"]
             if N == 1 and L == 256 and "hbm_bytes_per_launch" in kk:
-                traffic, traffic_src = kk["hbm_bytes_per_launch"], os.path.relpath(summary_path, ROOT)
+                traffic, traffic_src, rocprof_ms = kk["hbm_bytes_per_launch"], os.path.relpath(summary_path, ROOT), kk["avg_us"] * 1e-3
                 break
         except Exception:
             pass
@@ -429,6 +435,11 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "traffic_measured_in_run": False,
                      "avg_launch_ms": sweep_ms, "launches_timed": int(r["sweep_launches"]),
+                     # what the two hipEvent records themselves add to a bracketed launch (measured in this run around an
+                     # empty kernel); `frac` above is NOT corrected for it (conservative)
+                     "event_pair_overhead_ms": ev_over_ms,       # two records around an EMPTY kernel (its ~2-3 us included)
+                     "rocprof_avg_launch_ms": rocprof_ms,        # committed kernel trace of the same command (traffic_source)
+                     "frac_rocprof": (B_ALG_SWEEP * n_own / (rocprof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if rocprof_ms else None,
                      "launches_in_timed_region": int(r["full_sweeps"]),
                      "alg_bytes_per_voxel": B_ALG_SWEEP, "voxels_per_launch": n_own,
                      # BASELINE.md section 4 / SURVEY 8(d) pre-build accounting: 26.8 B per voxel per step (state u8 + T +

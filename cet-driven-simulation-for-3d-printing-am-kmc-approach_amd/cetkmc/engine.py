@@ -348,6 +348,13 @@ class Engine:
         self._ck(self.lib.cetkmc_time_sweeps(self.h, int(n), C.byref(ms)))
         return ms.value
 
+    def event_overhead(self, n=50):
+        """ms between two back-to-back hipEvents around an EMPTY kernel: the part of a hipEvent-bracketed kernel time that is
+        not the kernel's."""
+        ms = C.c_double(0.0)
+        self._ck(self.lib.cetkmc_event_overhead(self.h, int(n), C.byref(ms)))
+        return ms.value
+
     def set_option(self, key, value):
         self._ck(self.lib.cetkmc_set_option(self.h, key.encode(), int(value)))
 

@@ -1721,4 +1721,25 @@ int cetkmc_time_sweeps(void* handle, int n, double* ms_total)
     return 0;
 }
 
+int cetkmc_event_overhead(void* handle, int n, double* ms_avg)
+{
+    Handle* h = (Handle*)handle;
+    if (!h || !ms_avg || n < 1) return fail("bad argument");
+    HIPCHK(hipSetDevice(h->dev));
+    while ((int)h->prof.size() < 2 * n) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->prof.push_back(e); }
+    for (int q = 0; q < n; ++q) {
+        // a kernel before the pair as well: the bracketed launches of a batch follow other kernels back to back
+        hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, h->stream);
+        HIPCHK(hipEventRecord(h->prof[2 * q], h->stream));
+        hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, h->stream);
+        HIPCHK(hipEventRecord(h->prof[2 * q + 1], h->stream));
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double tot = 0.0;
+    for (int q = 0; q < n; ++q) { float t = 0.f; HIPCHK(hipEventElapsedTime(&t, h->prof[2 * q], h->prof[2 * q + 1])); tot += t; }
+    *ms_avg = tot / n;
+    return 0;
+}
+
 }  // extern "C"

@@ -1558,6 +1558,8 @@ __global__ __launch_bounds__(64) void k_apply_direct(KParams P, const SlabView* 
     apply_touch(P, slabs, nslabs, ktab_g, ev, threadIdx.x, 0, blockDim.x);
 }
 
+__global__ void k_empty() {}
+
 // start of a batch: the batch part of the step state (nucleation_count persists) -- on the stream, no host round trip
 __global__ void k_batch_reset(StepState* ss)
 {

@@ -282,6 +282,9 @@ int cetkmc_reset_counters(void* handle);
 /* Measurement helpers (bench.py): n back-to-back rate sweeps timed with hipEvents on the
  * engine's stream; returns total milliseconds. */
 int cetkmc_time_sweeps(void* handle, int n, double* ms_total);
+/* bench helper: average elapsed time between two hipEvents recorded back to back on the handle's stream, with one empty
+ * kernel between them (n pairs) -- what a hipEvent-bracketed kernel duration includes besides the kernel's own work */
+int cetkmc_event_overhead(void* handle, int n, double* ms_avg);
 
 #ifdef __cplusplus
 }
