@@ -33,8 +33,9 @@ def kname(raw):
 
 
 def one(pattern):
-    g = glob.glob(os.path.join(src, pattern))
-    return g[0] if g else None
+    """the NEWEST match: gpurun merges a re-run's files beside an earlier run's (different PIDs in the names)"""
+    g = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)
+    return g[-1] if g else None
 
 
 stats = one(f"{tag}_stats/*/*kernel_stats.csv")
