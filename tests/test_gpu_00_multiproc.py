@@ -210,3 +210,56 @@ def test_two_ranks_over_rccl_match_single_process(tmp_path):
         for k in ("state", "theta", "phi", "T", "defects"):
             assert np.array_equal(z[k], ref[k][i0:i1]), k
         assert np.array_equal(z["b_state"], ref["b_state"][i0:i1]) and np.array_equal(z["b_theta"], ref["b_theta"][i0:i1])
+
+
+# ---- defects.track_defects across ranks (config 5's refresh): every rank draws the same seeded stream and keeps its slice ----
+def _worker_defects(rank, world, port, L, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    root = os.path.dirname(HERE)
+    sys.path.insert(0, os.path.join(root, "cet-driven-simulation-for-3d-printing-am-kmc-approach_amd"))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cetkmc
+    import defects as defects_mod
+    from cetkmc import host_transport
+    fields, _ = _inputs(L, 1, 13)
+    state, theta, phi, T, dmask = fields
+
+    def rank_counts(n_mine):
+        box = [None] * world
+        dist.all_gather_object(box, int(n_mine))
+        return box
+
+    eng = cetkmc.Engine(L, impurity_c=0.2, device=0, rank=rank, nranks=world, host_comm=host_transport.torch_callbacks())
+    a0, a1 = max(0, eng.i0 - 2), min(L, eng.i1 + 2)
+    eng.upload_planes(a0, a1, state[a0:a1], theta[a0:a1], phi[a0:a1], T[a0:a1], dmask[a0:a1])
+    np.random.seed(99)
+    n_flag, _ = defects_mod.refresh_defects_device(eng, rank_counts=rank_counts, rank=rank)
+    after = np.random.random()                       # the stream position afterwards is the same on every rank
+    d = eng.download_planes(eng.i0, eng.i1, state=False, defects=True)["defects"]
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), defects=d, n_flag=n_flag, after=after, i0=eng.i0, i1=eng.i1)
+    eng.close()
+    dist.barrier()
+    if rank == 0:       # host reference: defects.track_defects on the whole lattice, same seed
+        np.random.seed(99)
+        mask = defects_mod.track_defects(state, state, L, T)
+        np.savez(os.path.join(out_dir, "ref.npz"), defects=mask, after=np.random.random())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,L", [(2, 16), (3, 24)])
+def test_defect_refresh_across_ranks_matches_host(world, L, tmp_path):
+    """refresh_defects_device(rank_counts=...) on slabs == defects.track_defects on the whole lattice (defects.py:4-19): same
+    flagged sites, same NumPy stream position afterwards on every rank."""
+    import torch.multiprocessing as mp
+    mp.spawn(_worker_defects, args=(world, _free_port(), L, str(tmp_path)), nprocs=world, join=True)
+    ref = np.load(tmp_path / "ref.npz")
+    total = 0
+    for rank in range(world):
+        z = np.load(tmp_path / f"rank{rank}.npz")
+        i0, i1 = int(z["i0"]), int(z["i1"])
+        assert np.array_equal(z["defects"] != 0, ref["defects"][i0:i1] != 0), rank
+        assert float(z["after"]) == float(ref["after"])
+        total += int(z["n_flag"])
+    assert total == int((ref["defects"] != 0).sum())
