@@ -89,7 +89,7 @@ struct Slab {
     double* Tbuf[2] = {nullptr, nullptr};
     double* vvalbuf[2] = {nullptr, nullptr};     // rate table of Tbuf[b] (the pair is flipped together)
     double* depbuf[2] = {nullptr, nullptr};      // plane L-1 deposition rates of Tbuf[b]
-    size_t nS = 0, nT = 0, nC = 0;   // bytes of a u8 array, doubles of an f64 array, u16s of the class array
+    size_t nS = 0, nT = 0, nC = 0;   // bytes of a u8 array, doubles of an f64 array, bytes of the class array
 };
 
 struct Handle {

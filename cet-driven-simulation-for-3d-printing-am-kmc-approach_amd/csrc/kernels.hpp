@@ -1,11 +1,15 @@
 // kernels.hpp -- HIP kernels of the KMC stepping engine (gfx950, wave64).
 //
-//   k_sweep         per-voxel rate evaluation + row reduction       (kmc_event_rates.py:162-176)
-//   k_plane_reduce  row sums -> block sums                          (kmc_simulation.py:259)
-//   k_select        canonical-tree descent to the chosen event      (kmc_simulation.py:265-274)
-//   k_apply*        lattice update + RNG bookkeeping                (kmc_simulation.py:276-327)
-//   k_thermal       7-point explicit Euler + clip                   (thermal_solver.py:36-117)
-//   k_enumerate     event list materialisation (parity / small L)   (kmc_event_rates.py:162-176)
+//   k_rate_table    per-voxel rate table from the temperature field      (kmc_event_rates.py:59-63,116-131)
+//   k_interface*    category sums of the listed interface voxels         (kmc_event_rates.py:93-107,134-158)
+//   k_sweep_stream  census + table lookup + canonical row reduction      (kmc_event_rates.py:162-176)
+//   k_sweep_simple  straightforward per-voxel evaluation (cross-check)   (kmc_event_rates.py:42-160)
+//   k_rows_eval     the same row reduction for the rows an event made stale (incremental mode)
+//   k_plane_reduce  row sums -> block sums                               (kmc_simulation.py:259)
+//   k_select*       canonical-tree descent to the chosen event           (kmc_simulation.py:265-274)
+//   k_apply*        lattice update + RNG bookkeeping + interface upkeep  (kmc_simulation.py:276-327)
+//   k_thermal*      7-point explicit Euler + clip                        (thermal_solver.py:36-117)
+//   k_enumerate     event list materialisation (parity / small L)        (kmc_event_rates.py:162-176)
 //   k_pack/k_unpack reference layout <-> padded device layout
 //
 // Canonical summation shape: voxel-category sums are sequential over the voxel's

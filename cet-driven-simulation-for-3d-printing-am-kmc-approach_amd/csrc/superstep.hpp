@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64) void k_domain_apply(KParams P, const SlabView* 
 }
 
 // Across ranks: the events of the neighbour ranks' boundary box layers (nb^2 boxes each, received after their own
-// k_domain_slot_apply) applied to this rank's copy -- write_site() clips to the slab + halo, so owned planes receive
+// k_domain_apply) applied to this rank's copy -- write_site() clips to the slab + halo, so owned planes receive
 // the diffusion targets that crossed the slab boundary and the halo planes stay a faithful copy of the neighbour.
 // recv[0 .. nb^2): layer below (global boxes d0 - nb^2 + q), recv[nb^2 .. 2 nb^2): layer above (d0 + D_loc + q').
 __global__ __launch_bounds__(64) void k_domain_apply_remote(const SlabView* __restrict__ slabs, int nslabs, SuperCfg C,
