@@ -91,6 +91,7 @@ _P = C.POINTER
 PROTOTYPES = {
     "cetkmc_last_error": (C.c_char_p, []),
     "cetkmc_abi_version": (C.c_int, []),
+    "cetkmc_source_hash": (C.c_char_p, []),
     "cetkmc_struct_size": (C.c_int, [C.c_char_p]),
     "cetkmc_device_count": (C.c_int, [_P(C.c_int)]),
     "cetkmc_create": (C.c_int, [_P(Params), C.c_int, C.c_int, _P(C.c_int), _P(C.c_void_p)]),
@@ -134,17 +135,43 @@ PROTOTYPES = {
 LAST_BUILD = None      # "compiled" | "reused" after build_library()
 
 
+def source_hash():
+    """sha256 (16 hex digits) over every source of the library, in name order: what the library reports through
+    cetkmc_source_hash() when it was compiled from exactly these files."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sources():
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def library_hash(so_path=None):
+    """the source hash compiled into an existing library, or None (missing file / library from before the hash)"""
+    so_path = so_path or SO_PATH
+    if not os.path.exists(so_path):
+        return None
+    try:
+        lib = C.CDLL(so_path)
+        fn = lib.cetkmc_source_hash
+        fn.restype = C.c_char_p
+        return fn().decode()
+    except (OSError, AttributeError):
+        return None
+
+
 def build_library(force=False, verbose=False):
-    """hipcc cross-compiles for gfx950 without a GPU; the .so stays in-tree (csrc/).  Recompiles when any source
-    (sources()) is newer than the library."""
+    """hipcc cross-compiles for gfx950 without a GPU; the .so stays in-tree (csrc/).  Recompiles when the library is missing
+    or was compiled from other sources than the ones beside it (source hash compiled in; file times are not trusted: a
+    checkout or a copy changes them)."""
     global LAST_BUILD
-    newest = max(os.path.getmtime(s) for s in sources())
-    if not force and os.path.exists(SO_PATH) and os.path.getmtime(SO_PATH) >= newest:
+    want = source_hash()
+    if not force and library_hash() == want:
         LAST_BUILD = "reused"
         return SO_PATH
     LAST_BUILD = "compiled"
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, "cetkmc_hip.hip"), "-o", SO_PATH, "-ldl"]
+    cmd = [hipcc] + HIPCC_FLAGS + [f'-DCETKMC_SRC_HASH="{want}"', os.path.join(CSRC, "cetkmc_hip.hip"), "-o", SO_PATH, "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
@@ -160,6 +187,9 @@ def load():
     if _lib is not None:
         return _lib
     so_path = os.environ.get("CETKMC_LIB", SO_PATH)       # alternative build of the same library (A/B timing only)
+    if "CETKMC_LIB" not in os.environ and os.path.exists(so_path) and library_hash(so_path) != source_hash() \
+            and os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+        build_library()        # a library compiled from other sources than the ones beside it: recompile (hipcc is here)
     if not os.path.exists(so_path):
         raise RuntimeError(
             f"{so_path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -171,6 +201,11 @@ def load():
         fn.argtypes = args
     if lib.cetkmc_abi_version() != 1:
         raise RuntimeError("libcetkmc_hip.so ABI version mismatch")
+    if "CETKMC_LIB" not in os.environ:        # (an explicitly chosen alternative build is the caller's business)
+        have, want = lib.cetkmc_source_hash().decode(), source_hash()
+        if have != want:
+            raise RuntimeError(f"{so_path} was compiled from other sources (hash {have}, sources {want}): rebuild it with "
+                               "`python -c 'import __graft_entry__ as g; g.build()'`")
     for name, mirror in STRUCT_MIRRORS.items():
         if lib.cetkmc_struct_size(name.encode()) != C.sizeof(mirror):
             raise RuntimeError(f"libcetkmc_hip.so: struct {name} is {lib.cetkmc_struct_size(name.encode())} bytes, "

@@ -883,6 +883,10 @@ extern "C" {
 
 const char* cetkmc_last_error(void) { return g_err.c_str(); }
 int cetkmc_abi_version(void) { return CETKMC_ABI_VERSION; }
+#ifndef CETKMC_SRC_HASH
+#define CETKMC_SRC_HASH "unknown"
+#endif
+const char* cetkmc_source_hash(void) { return CETKMC_SRC_HASH; }
 
 int cetkmc_struct_size(const char* name)
 {

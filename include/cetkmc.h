@@ -158,6 +158,9 @@ typedef struct cetkmc_counters {
 
 const char* cetkmc_last_error(void);
 int cetkmc_abi_version(void);
+/* hash of the sources the library was compiled from (-DCETKMC_SRC_HASH, set by cetkmc/_lib.build_library; "unknown" for a
+ * hand build): the binding compares it with the sources beside it and rebuilds / refuses a stale library */
+const char* cetkmc_source_hash(void);
 /* sizeof of an ABI struct by name ("params", "event", "sweep_info", "run_args", "run_result", "super_args", "counters",
  * "host_comm"); -1 for an unknown name.  Lets a binding check its mirrors against the library it loaded. */
 int cetkmc_struct_size(const char* name);
