@@ -147,17 +147,20 @@ def source_hash():
 
 
 def library_hash(so_path=None):
-    """the source hash compiled into an existing library, or None (missing file / library from before the hash)"""
+    """the source hash compiled into an existing library, or None (missing file / library from before the hash).  Read from
+    the file's bytes (marker "cetkmc-source-hash="), NOT by loading it: a library loaded once stays the one the process
+    sees under that path, also after build_library() has replaced the file."""
     so_path = so_path or SO_PATH
     if not os.path.exists(so_path):
         return None
-    try:
-        lib = C.CDLL(so_path)
-        fn = lib.cetkmc_source_hash
-        fn.restype = C.c_char_p
-        return fn().decode()
-    except (OSError, AttributeError):
+    marker = b"cetkmc-source-hash="
+    with open(so_path, "rb") as f:
+        data = f.read()
+    at = data.find(marker)
+    if at < 0:
         return None
+    end = data.find(b"\0", at)
+    return data[at + len(marker):end].decode(errors="replace")
 
 
 def build_library(force=False, verbose=False):

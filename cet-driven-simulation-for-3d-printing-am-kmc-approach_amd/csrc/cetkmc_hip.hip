@@ -886,7 +886,9 @@ int cetkmc_abi_version(void) { return CETKMC_ABI_VERSION; }
 #ifndef CETKMC_SRC_HASH
 #define CETKMC_SRC_HASH "unknown"
 #endif
-const char* cetkmc_source_hash(void) { return CETKMC_SRC_HASH; }
+// the hash follows a marker so that the binding can read it from the file without loading the library
+static const char g_src_hash[] = "cetkmc-source-hash=" CETKMC_SRC_HASH;
+const char* cetkmc_source_hash(void) { return g_src_hash + 19; }
 
 int cetkmc_struct_size(const char* name)
 {

@@ -28,6 +28,19 @@ def test_library_exports_header_symbols():
     assert lib.cetkmc_abi_version() == 1
 
 
+def test_library_hash_names_its_sources():
+    """The hash compiled into the library is the hash of csrc/*.hip, csrc/*.hpp, include/*.h beside it; the binding reads
+    it from the file's bytes (a dlopen of a stale file would pin that file for the rest of the process) and the loaded
+    library reports the same one."""
+    from cetkmc import _lib
+    _lib.build_library()
+    assert _lib.library_hash() == _lib.source_hash()
+    lib = _lib.load()
+    assert lib.cetkmc_source_hash().decode() == _lib.source_hash()
+    assert _lib.library_hash(os.path.join(ROOT, "include", "cetkmc.h")) is None      # a file without the marker
+    assert _lib.library_hash(os.path.join(ROOT, "no_such_file.so")) is None
+
+
 def test_struct_layouts_match_header():
     from cetkmc import _lib
     assert ctypes.sizeof(_lib.Event) == 64
