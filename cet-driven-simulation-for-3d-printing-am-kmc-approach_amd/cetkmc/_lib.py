@@ -129,6 +129,7 @@ PROTOTYPES = {
     "cetkmc_reset_counters": (C.c_int, [C.c_void_p]),
     "cetkmc_time_sweeps": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_double)]),
     "cetkmc_event_overhead": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_double)]),
+    "cetkmc_comm_selftest": (C.c_int, [C.c_void_p, C.c_int64, _P(C.c_double)]),
 }
 
 

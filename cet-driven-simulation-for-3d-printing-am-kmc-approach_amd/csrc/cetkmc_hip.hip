@@ -9,6 +9,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -1745,6 +1746,74 @@ int cetkmc_event_overhead(void* handle, int n, double* ms_avg)
     double tot = 0.0;
     for (int q = 0; q < n; ++q) { float t = 0.f; HIPCHK(hipEventElapsedTime(&t, h->prof[2 * q], h->prof[2 * q + 1])); tot += t; }
     *ms_avg = tot / n;
+    return 0;
+}
+
+// Transport self-test: every collective shape the stepping loops use, on patterned buffers, checked on the host.
+//   all-gather of `bytes` per rank (Mode A: block sums / event records) and the neighbour exchange of `bytes` each way
+//   (temperature halo, Mode B boundary layers).  A single-rank RCCL communicator sends to and receives from itself.
+// times_us (optional, 2 doubles): average of 20 back-to-back all-gathers / exchanges after the checked one.
+int cetkmc_comm_selftest(void* handle, int64_t bytes, double* times_us)
+{
+    Handle* h = (Handle*)handle;
+    if (!h || bytes < 1 || bytes > (1 << 26)) return fail("bad argument");
+    HIPCHK(hipSetDevice(h->dev));
+    if (times_us) times_us[0] = times_us[1] = 0.0;
+    if (!multi_rank(h)) return 0;
+    const int R = h->nranks, me = h->rank;
+    const size_t B = (size_t)bytes;
+    auto pat = [](int from, int tag, size_t q) -> unsigned char { return (unsigned char)(from * 37 + tag * 101 + q * 7 + (q >> 8)); };
+    char* d = nullptr;          // [gather: R*B | send_lo | send_hi | recv_lo | recv_hi]
+    HIPCHK(hipMalloc(&d, (R + 4) * B));
+    std::vector<unsigned char> host((R + 4) * B, 0xEE);
+    for (size_t q = 0; q < B; ++q) {
+        host[me * B + q] = pat(me, 0, q);
+        host[(R + 0) * B + q] = pat(me, 1, q);      // to rank-1
+        host[(R + 1) * B + q] = pat(me, 2, q);      // to rank+1
+    }
+    HIPCHK(hipMemcpy(d, host.data(), host.size(), hipMemcpyHostToDevice));
+    int rc = comm_allgather(h, d, B);
+    if (!rc) {
+        if (h->comm && R == 1) {            // loopback: the Send/Recv signatures and group semantics on this build of RCCL
+            NCCLCHK(g_rccl.GroupStart());
+            NCCLCHK(g_rccl.Send(d + (R + 0) * B, B, ncclChar, 0, h->comm, h->stream));
+            NCCLCHK(g_rccl.Recv(d + (R + 2) * B, B, ncclChar, 0, h->comm, h->stream));
+            NCCLCHK(g_rccl.GroupEnd());
+        } else {
+            rc = comm_exchange(h, d + (R + 0) * B, d + (R + 2) * B, d + (R + 1) * B, d + (R + 3) * B, B);
+        }
+    }
+    if (rc) { (void)hipFree(d); return rc; }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(host.data(), d, host.size(), hipMemcpyDeviceToHost));
+    std::string bad;
+    for (int r = 0; r < R && bad.empty(); ++r)
+        for (size_t q = 0; q < B; ++q)
+            if (host[r * B + q] != pat(r, 0, q)) { bad = "all-gather: part of rank " + std::to_string(r) + " wrong at byte " + std::to_string(q); break; }
+    if (bad.empty() && h->comm && R == 1) {
+        for (size_t q = 0; q < B; ++q) if (host[(R + 2) * B + q] != pat(0, 1, q)) { bad = "loopback send/recv wrong at byte " + std::to_string(q); break; }
+    } else if (bad.empty()) {
+        for (size_t q = 0; q < B && bad.empty(); ++q) {
+            // from rank-1 comes what it sent "to rank+1" (tag 2); from rank+1 what it sent "to rank-1" (tag 1)
+            if (me > 0 && host[(R + 2) * B + q] != pat(me - 1, 2, q)) bad = "exchange: data from rank-1 wrong at byte " + std::to_string(q);
+            if (me < R - 1 && host[(R + 3) * B + q] != pat(me + 1, 1, q)) bad = "exchange: data from rank+1 wrong at byte " + std::to_string(q);
+            if (me == 0 && host[(R + 2) * B + q] != 0xEE) bad = "exchange: end rank's unused receive buffer was written";
+        }
+    }
+    if (!bad.empty()) { (void)hipFree(d); return fail("transport self-test (rank " + std::to_string(me) + "): " + bad); }
+    if (times_us) {
+        for (int leg = 0; leg < 2; ++leg) {
+            HIPCHK(hipStreamSynchronize(h->stream));
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int q = 0; q < 20 && !rc; ++q)
+                rc = leg == 0 ? comm_allgather(h, d, B)
+                              : comm_exchange(h, d + (R + 0) * B, d + (R + 2) * B, d + (R + 1) * B, d + (R + 3) * B, B);
+            if (rc) { (void)hipFree(d); return rc; }
+            HIPCHK(hipStreamSynchronize(h->stream));
+            times_us[leg] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 20.0;
+        }
+    }
+    HIPCHK(hipFree(d));
     return 0;
 }
 

@@ -288,6 +288,11 @@ int cetkmc_time_sweeps(void* handle, int n, double* ms_total);
 /* bench helper: average elapsed time between two hipEvents recorded back to back on the handle's stream, with one empty
  * kernel between them (n pairs) -- what a hipEvent-bracketed kernel duration includes besides the kernel's own work */
 int cetkmc_event_overhead(void* handle, int n, double* ms_avg);
+/* Transport self-test of a multi-rank handle (collective: every rank calls it with the same `bytes`): patterned buffers
+ * through the all-gather and the neighbour exchange the stepping loops use, verified on the host; a single-rank RCCL
+ * communicator sends to itself.  times_us (may be NULL) receives the average wall time in microseconds of 20 further
+ * all-gathers [0] and neighbour exchanges [1] of that size, stream synchronisation included.  Single-process handle: no-op. */
+int cetkmc_comm_selftest(void* handle, int64_t bytes, double* times_us);
 
 #ifdef __cplusplus
 }

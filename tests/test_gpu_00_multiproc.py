@@ -57,6 +57,9 @@ def _worker(rank, world, port, L, n, seed, mode, out_dir):
     fields, streams = _inputs(L, n, seed)
     eng = cetkmc.Engine(L, impurity_c=0.2, device=0, rank=rank, nranks=world, host_comm=host_transport.torch_callbacks())
     a0, a1 = max(0, eng.i0 - 2), min(L, eng.i1 + 2)
+    for nbytes in (64, 5000):       # transport self-test: patterned all-gather + neighbour exchange, checked by the library
+        t = eng.comm_selftest(nbytes)
+        assert t["allgather_us"] > 0 and t["exchange_us"] > 0
     r, d, info = _run(eng, a0, a1, fields, streams, n, mode)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), totals=r["totals"], events=r["events"], n_events=r["n_events"],
              np_used=r["np_used"], i0=eng.i0, i1=eng.i1, info=np.array(info, dtype=np.float64), **d)
@@ -171,6 +174,8 @@ def _worker_rccl(rank, world, port, L, n, seed, out_dir):
     fields, streams = _inputs(L, n, seed)
     eng = cetkmc.Engine(L, impurity_c=0.2, device=rank, rank=rank, nranks=world, unique_id=box[0])
     a0, a1 = max(0, eng.i0 - 2), min(L, eng.i1 + 2)
+    eng.comm_selftest(64)
+    eng.comm_selftest(2 * L * L * 8)
     r, d, info = _run(eng, a0, a1, fields, streams, n, "full")
     rb = eng.run_supersteps(n, 16, 8, 0.05, seed=9, thermal_mode=1, want_events=True)
     db = eng.download_planes(eng.i0, eng.i1, state=True, theta=True)

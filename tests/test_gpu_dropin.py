@@ -123,6 +123,9 @@ def test_rccl_single_rank_mode():
             e = cetkmc.Engine(L, impurity_c=0.2)
         else:
             e = cetkmc.Engine(L, impurity_c=0.2, rank=0, nranks=1, unique_id=cetkmc.Engine.unique_id())
+            # patterned all-gather + a send/recv to itself through RCCL (the neighbour-exchange calls of N > 1), data checked
+            t = e.comm_selftest(4096)
+            assert t["allgather_us"] > 0
         if mode == "rank+overlap":
             e.set_option("interface_every_step", 1)
         e.upload(state, theta, phi, T, defects)
