@@ -117,6 +117,7 @@ PROTOTYPES = {
     "cetkmc_enumerate_events": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _P(C.c_int64)]),
     "cetkmc_row_sums": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cetkmc_run_steps": (C.c_int, [C.c_void_p, _P(RunArgs), _P(RunResult), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cetkmc_stage_inputs": (C.c_int, [C.c_void_p, _P(RunArgs)]),
     "cetkmc_run_supersteps": (C.c_int, [C.c_void_p, _P(SuperArgs), _P(RunResult), C.c_void_p, C.c_void_p, C.c_void_p]),
     "cetkmc_get_counters": (C.c_int, [C.c_void_p, _P(Counters), C.c_int]),
     "cetkmc_cluster": (C.c_int, [C.c_void_p, C.c_double, _P(C.c_int64)]),

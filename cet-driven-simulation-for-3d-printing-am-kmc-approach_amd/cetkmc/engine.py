@@ -241,8 +241,8 @@ class Engine:
         return rs, rc
 
     # -- batched loop ------------------------------------------------------------------------
-    def run_steps(self, step0, n, defect_fraction, u_pick, u_defect, u_np, rng_mode=0, seed=0, thermal_mode=1,
-                  thermal_dt=1e-6, q_planes=None, use_latent=True, profile=False, want_logs=True, incremental=False):
+    def _run_args(self, step0, n, defect_fraction, u_pick, u_defect, u_np, rng_mode, seed, thermal_mode, thermal_dt, q_planes,
+                  use_latent, profile, incremental):
         a = RunArgs()
         u_pick = np.ascontiguousarray(u_pick, dtype=np.float64)
         u_defect = None if u_defect is None else np.ascontiguousarray(u_defect, dtype=np.float64)
@@ -255,6 +255,22 @@ class Engine:
         a.q_planes, a.n_q = _dptr(q), (0 if q is None else q.shape[0])
         a.use_latent, a.profile = int(bool(use_latent)), int(profile)       # profile: False/True/2 (per-phase, see counters())
         a.incremental = int(bool(incremental))
+        return a, (u_pick, u_defect, u_np, q)       # (the arrays stay referenced while the pointers are in use)
+
+    def stage_inputs(self, step0, n, defect_fraction, u_pick, u_defect, u_np, rng_mode=0, seed=0, thermal_mode=1,
+                     thermal_dt=1e-6, q_planes=None, use_latent=True, profile=False, incremental=False):
+        """cetkmc_stage_inputs: the batch's random streams and laser source planes go to the device NOW; the matching
+        run_steps(..., staged=True) call copies nothing."""
+        a, keep = self._run_args(step0, n, defect_fraction, u_pick, u_defect, u_np, rng_mode, seed, thermal_mode, thermal_dt,
+                                 q_planes, use_latent, profile, incremental)
+        self._ck(self.lib.cetkmc_stage_inputs(self.h, C.byref(a)))
+
+    def run_steps(self, step0, n, defect_fraction, u_pick, u_defect, u_np, rng_mode=0, seed=0, thermal_mode=1,
+                  thermal_dt=1e-6, q_planes=None, use_latent=True, profile=False, want_logs=True, incremental=False, staged=False):
+        a, keep = self._run_args(step0, n, defect_fraction, u_pick, u_defect, u_np, rng_mode, seed, thermal_mode, thermal_dt,
+                                 q_planes, use_latent, profile, incremental)
+        if staged:       # same arguments as the stage_inputs call; the library checks the batch shape and copies nothing
+            a.u_pick = a.u_defect = a.u_np = a.q_planes = None
         res = RunResult()
         totals = np.zeros(n + 1, np.float64) if want_logs else None
         events = np.zeros(max(n, 1), dtype=EVENT_DTYPE) if want_logs else None

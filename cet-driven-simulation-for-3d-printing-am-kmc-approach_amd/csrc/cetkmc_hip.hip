@@ -119,6 +119,12 @@ struct Handle {
     cetkmc_event* d_log_event = nullptr;
     int64_t* d_log_nev = nullptr;
     size_t cap_steps = 0, cap_np = 0, cap_q = 0;
+    // page-locked host staging for a batch's inputs and logs: copies to / from it are queued on the stream like kernels
+    // (a copy to or from pageable memory blocks the caller once per array)
+    char* pin_in = nullptr; size_t pin_in_cap = 0;
+    char* pin_out = nullptr; size_t pin_out_cap = 0;
+    // a batch whose host inputs are already in d_u_pick / d_u_defect / d_u_np / d_q (cetkmc_stage_inputs)
+    struct { bool valid = false, has_defect = false; int64_t step0 = 0, n_steps = 0, np_cap = 0, n_q = 0; int thermal_mode = 0; } staged;
     // rccl
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
@@ -848,6 +854,17 @@ int grow(T** p, size_t* cap, size_t need)
     return 0;
 }
 
+int grow_pinned(char** p, size_t* cap, size_t need)
+{
+    if (*cap >= need) return 0;
+    if (*p) { HIPCHK(hipHostFree(*p)); *p = nullptr; *cap = 0; }
+    const size_t c = std::max<size_t>(need + need / 2, 1 << 16);
+    HIPCHK(hipHostMalloc((void**)p, c, hipHostMallocDefault));
+    *cap = c;
+    return 0;
+}
+constexpr size_t PIN_SMALL_MAX = 1 << 20;      // larger arrays (long u_np streams, many source planes) are copied directly
+
 void destroy_impl(Handle* h)
 {
     if (!h) return;
@@ -867,6 +884,8 @@ void destroy_impl(Handle* h)
                     h->d_flag, h->d_qtop, h->d_u_pick, h->d_u_defect, h->d_u_np, h->d_q, h->d_log_total,
                     h->d_log_event, h->d_log_nev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (h->pin_in) (void)hipHostFree(h->pin_in);
+    if (h->pin_out) (void)hipHostFree(h->pin_out);
     for (auto e : h->prof) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1022,6 +1041,8 @@ int cetkmc_set_option(void* handle, const char* key, int64_t value)
         h->cap_steps = std::min({c1, c2, c3, c4, c5});
         CHK(grow(&h->d_u_np, &h->cap_np, 2 * n + 2 + (size_t)h->L * h->L));
         CHK(grow(&h->d_q, &h->cap_q, (n / 20 + 2) * (size_t)h->L * h->L));
+        CHK(grow_pinned(&h->pin_in, &h->pin_in_cap, 2 * n * 8 + (2 * n + 2) * 8 + std::min<size_t>(PIN_SMALL_MAX, (n / 20 + 2) * (size_t)h->L * h->L * 8)));
+        CHK(grow_pinned(&h->pin_out, &h->pin_out_cap, 64 + n * (16 + sizeof(cetkmc_event)) + h->slabs.size() * sizeof(int)));
         // events: the per-phase mode (7 per step) is used on short batches only; the sampled modes need 2 per (8th) step
         const int64_t need = std::max<int64_t>(7 * std::min<int64_t>(value, 256), value <= 64 ? 2 * value : 2 * (value / 8 + 1));
         while ((int64_t)h->prof.size() < need) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->prof.push_back(e); }
@@ -1247,38 +1268,100 @@ int cetkmc_enumerate_events(void* handle, cetkmc_event* buf, int64_t cap, int64_
     return 0;
 }
 
+// host inputs of a batch -> the handle's device buffers (grown as needed); shared by cetkmc_stage_inputs / cetkmc_run_steps
+static int check_run_args(Handle* h, const cetkmc_run_args* a, bool need_ptrs, int64_t* n_therm_out)
+{
+    const int64_t n = a->n_steps;
+    if (n < 0) return fail("n_steps < 0");
+    if (need_ptrs && n > 0 && !a->u_pick) return fail("u_pick required");
+    if (need_ptrs && a->defect_fraction > 0.0 && n > 0 && !a->u_defect) return fail("u_defect required when defect_fraction > 0");
+    if (need_ptrs && a->np_cap > 0 && !a->u_np) return fail("u_np required");
+    int64_t n_therm = 0;
+    if (a->thermal_mode) for (int64_t s = 0; s < n; ++s) if ((a->step0 + s) % 20 == 0) ++n_therm;
+    if (a->thermal_mode == 2 && (n_therm > a->n_q || (need_ptrs && n_therm > 0 && !a->q_planes)))
+        return fail("thermal_mode 2 needs one q plane per thermal update in the batch");
+    *n_therm_out = n_therm;
+    (void)h;
+    return 0;
+}
+
+static int upload_run_inputs(Handle* h, const cetkmc_run_args* a, int64_t n_therm)
+{
+    const int64_t n = a->n_steps;
+    const size_t L2 = (size_t)h->L * h->L;
+    size_t c1 = h->cap_steps, c2 = h->cap_steps, c3 = h->cap_steps, c4 = h->cap_steps, c5 = h->cap_steps;
+    CHK(grow(&h->d_u_pick, &c1, (size_t)n));
+    CHK(grow(&h->d_u_defect, &c2, (size_t)n));
+    CHK(grow(&h->d_log_total, &c3, (size_t)n));
+    CHK(grow(&h->d_log_event, &c4, (size_t)n));
+    CHK(grow(&h->d_log_nev, &c5, (size_t)n));
+    h->cap_steps = std::min({c1, c2, c3, c4, c5});
+    CHK(grow(&h->d_u_np, &h->cap_np, (size_t)std::max<int64_t>(a->np_cap, 2)));
+    if (a->thermal_mode == 2) CHK(grow(&h->d_q, &h->cap_q, (size_t)std::max<int64_t>(n_therm, 1) * L2));
+    // the small arrays travel through the page-locked staging buffer (queued copies); a large one goes directly
+    struct Part { void* dst; const void* src; size_t bytes; };
+    const Part parts[4] = {{h->d_u_pick, a->u_pick, n > 0 ? (size_t)n * 8 : 0},
+                           {h->d_u_defect, a->u_defect, (n > 0 && a->u_defect) ? (size_t)n * 8 : 0},
+                           {h->d_u_np, a->u_np, a->np_cap > 0 ? (size_t)a->np_cap * 8 : 0},
+                           {h->d_q, a->q_planes, (a->thermal_mode == 2 && n_therm > 0) ? (size_t)n_therm * L2 * 8 : 0}};
+    size_t small = 0;
+    for (const Part& q : parts) if (q.bytes && q.bytes <= PIN_SMALL_MAX) small += q.bytes;
+    // the staging buffer may still feed the copies of the previous call: they are complete (every stepping call ends with a
+    // stream synchronisation), so it can be rewritten
+    CHK(grow_pinned(&h->pin_in, &h->pin_in_cap, small));
+    size_t off = 0;
+    for (const Part& q : parts) {
+        if (!q.bytes) continue;
+        if (q.bytes <= PIN_SMALL_MAX) {
+            memcpy(h->pin_in + off, q.src, q.bytes);
+            HIPCHK(hipMemcpyAsync(q.dst, h->pin_in + off, q.bytes, hipMemcpyHostToDevice, h->stream));
+            off += q.bytes;
+        } else {
+            HIPCHK(hipMemcpyAsync(q.dst, q.src, q.bytes, hipMemcpyHostToDevice, h->stream));
+        }
+    }
+    h->cnt.bytes_h2d += (n > 0 ? n * 8 : 0) + (n > 0 && a->u_defect ? n * 8 : 0) + std::max<int64_t>(a->np_cap, 0) * 8 +
+                        (a->thermal_mode == 2 ? n_therm * (int64_t)L2 * 8 : 0);
+    return 0;
+}
+
+int cetkmc_stage_inputs(void* handle, const cetkmc_run_args* a)
+{
+    Handle* h = (Handle*)handle;
+    if (!h || !a) return fail("null argument");
+    int64_t n_therm = 0;
+    h->staged.valid = false;
+    CHK(check_run_args(h, a, true, &n_therm));
+    HIPCHK(hipSetDevice(h->dev));
+    CHK(upload_run_inputs(h, a, n_therm));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->staged.valid = true;
+    h->staged.step0 = a->step0; h->staged.n_steps = a->n_steps; h->staged.np_cap = a->np_cap; h->staged.n_q = a->n_q;
+    h->staged.thermal_mode = a->thermal_mode; h->staged.has_defect = a->u_defect != nullptr;
+    return 0;
+}
+
 int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* res, double* totals,
                      cetkmc_event* events, int64_t* n_events)
 {
     Handle* h = (Handle*)handle;
     if (!h || !a || !res) return fail("null argument");
     const int64_t n = a->n_steps;
-    if (n < 0) return fail("n_steps < 0");
-    if (n > 0 && !a->u_pick) return fail("u_pick required");
-    if (a->defect_fraction > 0.0 && n > 0 && !a->u_defect) return fail("u_defect required when defect_fraction > 0");
-    if (a->np_cap > 0 && !a->u_np) return fail("u_np required");
+    // all input pointers NULL: the batch's inputs were put on the device by cetkmc_stage_inputs (same batch shape)
+    const bool staged = n > 0 && !a->u_pick && !a->u_defect && !a->u_np && !a->q_planes;
     int64_t n_therm = 0;
-    if (a->thermal_mode) for (int64_t s = 0; s < n; ++s) if ((a->step0 + s) % 20 == 0) ++n_therm;
-    if (a->thermal_mode == 2 && (n_therm > a->n_q || (n_therm > 0 && !a->q_planes)))
-        return fail("thermal_mode 2 needs one q plane per thermal update in the batch");
+    CHK(check_run_args(h, a, !staged, &n_therm));
+    const auto g = h->staged;
+    h->staged.valid = false;           // a staged batch is consumed (or dropped) by the next stepping call
+    if (staged) {
+        if (!g.valid) return fail("no input pointers and no staged batch (cetkmc_stage_inputs)");
+        if (g.step0 != a->step0 || g.n_steps != n || g.np_cap != a->np_cap || g.n_q != a->n_q || g.thermal_mode != a->thermal_mode ||
+            (a->defect_fraction > 0.0 && !g.has_defect))
+            return fail("the staged batch (cetkmc_stage_inputs) does not match this call's step0 / n_steps / np_cap / n_q / thermal_mode");
+    }
     HIPCHK(hipSetDevice(h->dev));
     const size_t L2 = (size_t)h->L * h->L;
-    {
-        size_t c1 = h->cap_steps, c2 = h->cap_steps, c3 = h->cap_steps, c4 = h->cap_steps, c5 = h->cap_steps;
-        CHK(grow(&h->d_u_pick, &c1, (size_t)n));
-        CHK(grow(&h->d_u_defect, &c2, (size_t)n));
-        CHK(grow(&h->d_log_total, &c3, (size_t)n));
-        CHK(grow(&h->d_log_event, &c4, (size_t)n));
-        CHK(grow(&h->d_log_nev, &c5, (size_t)n));
-        h->cap_steps = std::min({c1, c2, c3, c4, c5});
-        CHK(grow(&h->d_u_np, &h->cap_np, (size_t)std::max<int64_t>(a->np_cap, 2)));
-        if (a->thermal_mode == 2) CHK(grow(&h->d_q, &h->cap_q, (size_t)std::max<int64_t>(n_therm, 1) * L2));
-    }
-    if (n > 0) HIPCHK(hipMemcpyAsync(h->d_u_pick, a->u_pick, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
-    if (n > 0 && a->u_defect) HIPCHK(hipMemcpyAsync(h->d_u_defect, a->u_defect, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
-    if (a->np_cap > 0) HIPCHK(hipMemcpyAsync(h->d_u_np, a->u_np, (size_t)a->np_cap * 8, hipMemcpyHostToDevice, h->stream));
-    if (a->thermal_mode == 2 && n_therm > 0)
-        HIPCHK(hipMemcpyAsync(h->d_q, a->q_planes, (size_t)n_therm * L2 * 8, hipMemcpyHostToDevice, h->stream));
+    if (!staged) CHK(upload_run_inputs(h, a, n_therm));
     // reset the batch part of the step state (nucleation_count persists): a one-thread kernel, no host round trip
     StepState ss;
     hipLaunchKernelGGL(k_batch_reset, dim3(1), dim3(1), 0, h->stream, h->d_ss);
@@ -1299,8 +1382,6 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
     auto pev = [&](int64_t s, int q) -> hipEvent_t { return a->profile == 2 ? h->prof[EPS * s + q] : nullptr; };
     std::vector<char> was_thermal, was_full;
     if (a->profile == 2) { was_thermal.assign((size_t)n, 0); was_full.assign((size_t)n, 0); }
-    h->cnt.bytes_h2d += (n > 0 ? n * 8 : 0) + (n > 0 && a->u_defect ? n * 8 : 0) + std::max<int64_t>(a->np_cap, 0) * 8 +
-                        (a->thermal_mode == 2 ? n_therm * (int64_t)L2 * 8 : 0);
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     int64_t q_idx = 0;
     const bool incr = a->incremental && h->sweep_variant >= 1;
@@ -1350,14 +1431,23 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     // everything the host wants back travels behind ONE synchronisation: step state, the per-step logs (all n entries;
     // only the first steps_done are meaningful) and the interface lists' lengths
-    HIPCHK(hipMemcpyAsync(&ss, h->d_ss, sizeof ss, hipMemcpyDeviceToHost, h->stream));
-    if (totals && n > 0) HIPCHK(hipMemcpyAsync(totals, h->d_log_total, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
-    if (events && n > 0) HIPCHK(hipMemcpyAsync(events, h->d_log_event, (size_t)n * sizeof(cetkmc_event), hipMemcpyDeviceToHost, h->stream));
-    if (n_events && n > 0) HIPCHK(hipMemcpyAsync(n_events, h->d_log_nev, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
-    std::vector<int> list_len(h->slabs.size(), 0);
-    for (size_t sl = 0; sl < h->slabs.size(); ++sl)
-        HIPCHK(hipMemcpyAsync(&list_len[sl], h->slabs[sl].v.ifc_n, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    const size_t nsl = h->slabs.size();
+    const size_t o_tot = 64, o_ev = o_tot + (size_t)n * 8, o_nev = o_ev + (size_t)n * sizeof(cetkmc_event), o_len = o_nev + (size_t)n * 8;
+    static_assert(sizeof(StepState) <= 64, "StepState grew: move the log offsets");
+    CHK(grow_pinned(&h->pin_out, &h->pin_out_cap, o_len + nsl * sizeof(int)));
+    HIPCHK(hipMemcpyAsync(h->pin_out, h->d_ss, sizeof ss, hipMemcpyDeviceToHost, h->stream));
+    if (totals && n > 0) HIPCHK(hipMemcpyAsync(h->pin_out + o_tot, h->d_log_total, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+    if (events && n > 0) HIPCHK(hipMemcpyAsync(h->pin_out + o_ev, h->d_log_event, (size_t)n * sizeof(cetkmc_event), hipMemcpyDeviceToHost, h->stream));
+    if (n_events && n > 0) HIPCHK(hipMemcpyAsync(h->pin_out + o_nev, h->d_log_nev, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+    std::vector<int> list_len(nsl, 0);
+    for (size_t sl = 0; sl < nsl; ++sl)
+        HIPCHK(hipMemcpyAsync(h->pin_out + o_len + sl * sizeof(int), h->slabs[sl].v.ifc_n, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    memcpy(&ss, h->pin_out, sizeof ss);
+    if (totals && n > 0) memcpy(totals, h->pin_out + o_tot, (size_t)n * 8);
+    if (events && n > 0) memcpy(events, h->pin_out + o_ev, (size_t)n * sizeof(cetkmc_event));
+    if (n_events && n > 0) memcpy(n_events, h->pin_out + o_nev, (size_t)n * 8);
+    if (nsl) memcpy(list_len.data(), h->pin_out + o_len, nsl * sizeof(int));
     if (h->spec.valid) { HIPCHK(hipStreamSynchronize(h->stream2)); h->spec.valid = false; }      // never outlives its batch
     res->steps_done = ss.cur; res->status = ss.status; res->np_used = ss.np_pos; res->q_used = q_idx;
     res->nucleation_count = ss.nuc_count;
@@ -1449,6 +1539,7 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
     C.D_loc = D;
     const int NE = D + 2 * nb2;                               // own events | lower neighbour's top layer | upper neighbour's bottom layer
     const size_t shmem = (size_t)C.PT * C.PH * C.PH * 19;     // heap: 2*NL doubles + 2*NL flags, NL leaf codes
+    h->staged.valid = false;            // the batch buffers are reused below
     {
         size_t c1 = h->cap_steps, c2 = h->cap_steps, c3 = h->cap_steps, c4 = h->cap_steps, c5 = h->cap_steps;
         CHK(grow(&h->d_u_pick, &c1, (size_t)n));

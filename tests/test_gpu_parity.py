@@ -776,3 +776,38 @@ def test_thermal_lookahead_option_identical(n_slabs, thermal_mode):
         outs.append((res, rb["totals"].tobytes(), rb["n_exec"].tobytes(), {k: v.tobytes() for k, v in d.items()}, e.rate_sweep()))
         e.close()
     assert outs[0] == outs[1]
+
+
+def test_staged_inputs_identical_and_checked():
+    """cetkmc_stage_inputs: a batch whose streams / source planes were copied ahead gives the same bits as the plain call;
+    the library refuses a staged call whose shape differs from the staged batch, and a staged batch is used once."""
+    import cetkmc
+    from cetkmc import synthetic
+    L, n = 32, 45
+    st, th, ph, T, df = synthetic.planes(L, 0, L, seed=8)
+    rs = np.random.RandomState(2)
+    u_pick, u_def, u_np = rs.random_sample(n), rs.random_sample(n), rs.random_sample(2 * n + 2)
+    q = synthetic.laser_planes(L, 10, n)
+    args = (10, n, 0.05, u_pick, u_def, u_np)
+    kw = dict(rng_mode=1, seed=4, thermal_mode=2, q_planes=q)
+    outs = []
+    for staged in (False, True):
+        e = cetkmc.Engine(L, impurity_c=0.2)
+        e.upload_planes(0, L, st, th, ph, T, df)
+        e.set_prev_state(None)
+        if staged:
+            with pytest.raises(RuntimeError, match="no staged batch"):
+                e.run_steps(*args, staged=True, **kw)
+            e.stage_inputs(*args, **kw)
+            with pytest.raises(RuntimeError, match="does not match"):
+                e.run_steps(11, n, 0.05, u_pick, u_def, u_np, staged=True, **kw)
+            e.stage_inputs(*args, **kw)             # (the refused call dropped the staged batch)
+        r = e.run_steps(*args, staged=staged, **kw)
+        assert r["done"] == n and r["status"] == 0
+        if staged:
+            with pytest.raises(RuntimeError, match="no staged batch"):
+                e.run_steps(*args, staged=True, **kw)
+        d = e.download_planes(0, L, state=True, theta=True, phi=True, T=True, defects=True)
+        outs.append((r["totals"].tobytes(), r["events"].tobytes(), r["np_used"], {k: v.tobytes() for k, v in d.items()}))
+        e.close()
+    assert outs[0] == outs[1]
