@@ -131,7 +131,7 @@ struct Handle {
     bool swept = false;
     int sweep_variant = 1;     // 0 simple, 1 streaming + rate table (default), 2 streaming, nucleation rates recomputed per sweep
     bool table_fresh = false;  // vval / dep_val match the current T and parameters (k_rate_table)
-    bool ifc_fresh = false;    // vval / ifc_cnt of every listed voxel match the current lattice, T, defects and parameters
+    bool ifc_fresh = false;    // vval / event count (class byte) of every listed voxel match the current lattice, T, defects and parameters
     int ifc_every_step = 0;    // 1: k_interface before every full sweep (round-1 behaviour, A/B); 0: only when stale --
                                // between temperature updates the apply kernel re-evaluates the <= 30 listed voxels an event touches
     int thermal_variant = 1;   // 1 = plane-marching LDS kernel, 0 = one thread per voxel
@@ -287,13 +287,11 @@ int create_common(const cetkmc_params* p, int L, const std::vector<std::pair<int
             HIPCHK(hipMemsetAsync(s.depbuf[b], 0, (size_t)L * h->pitchT * sizeof(double), h->stream));
         }
         s.v.vval = s.vvalbuf[0]; s.v.dep_val = s.depbuf[0];
-        HIPCHK(hipMalloc((void**)&s.v.ifc_cnt, s.nT));
         HIPCHK(hipMalloc((void**)&s.v.ifc_in, s.nT));
         HIPCHK(hipMalloc((void**)&s.v.ifc_code, s.nT * sizeof(uint32_t)));
         HIPCHK(hipMemsetAsync(s.v.ifc_code, 0xFF, s.nT * sizeof(uint32_t), h->stream));
         HIPCHK(hipMalloc((void**)&s.v.ifc_list, (size_t)r.second * L * L * sizeof(uint32_t)));
         HIPCHK(hipMalloc((void**)&s.v.ifc_n, sizeof(int)));
-        HIPCHK(hipMemsetAsync(s.v.ifc_cnt, 0, s.nT, h->stream));
         HIPCHK(hipMemsetAsync(s.v.ifc_in, 0, s.nT, h->stream));
         HIPCHK(hipMemsetAsync(s.v.ifc_n, 0, sizeof(int), h->stream));
         HIPCHK(hipMalloc((void**)&s.v.rowsum, (size_t)r.second * 3 * L * sizeof(double)));
@@ -525,7 +523,7 @@ StreamArgs stream_args(Handle* h, const SlabView& v)
     sa.T_melt = h->kp.T_melt; sa.delta_T_c = h->kp.delta_T_c; sa.kT = h->kp.kT; sa.I0 = h->kp.I0;
     sa.rate_threshold = h->kp.rate_threshold; sa.K0 = host_k_eff(h->p, 0, 0);
     sa.L = v.L; sa.gi0 = v.gi0; sa.nloc = v.nloc; sa.RJ = v.RJ; sa.pitchC = v.pitchC; sa.pitchT = v.pitchT; sa.Pk = v.Pk;
-    sa.cls = v.cls; sa.T = v.T; sa.vval = v.vval; sa.ifc_cnt = v.ifc_cnt; sa.dep_val = v.dep_val; sa.rowsum = v.rowsum; sa.rowcnt = v.rowcnt;
+    sa.cls = v.cls; sa.T = v.T; sa.vval = v.vval; sa.dep_val = v.dep_val; sa.rowsum = v.rowsum; sa.rowcnt = v.rowcnt;
     sa.group_first = 0; sa.group_count = (v.nloc + STREAM_NI - 1) / STREAM_NI;
     return sa;
 }
@@ -876,7 +874,7 @@ void destroy_impl(Handle* h)
         (void)hipFree(s.v.state); (void)hipFree(s.v.defects); (void)hipFree(s.prev); (void)hipFree(s.v.row_chg); (void)hipFree(s.v.cls);
         (void)hipFree(s.Tbuf[0]); (void)hipFree(s.Tbuf[1]); (void)hipFree(s.v.theta); (void)hipFree(s.v.phi); (void)hipFree(s.v.ovec);
         (void)hipFree(s.v.rowsum); (void)hipFree(s.v.rowcnt);
-        (void)hipFree(s.vvalbuf[0]); (void)hipFree(s.vvalbuf[1]); (void)hipFree(s.depbuf[0]); (void)hipFree(s.depbuf[1]); (void)hipFree(s.v.ifc_cnt); (void)hipFree(s.v.ifc_in); (void)hipFree(s.v.ifc_code); (void)hipFree(s.v.ifc_list); (void)hipFree(s.v.ifc_n);
+        (void)hipFree(s.vvalbuf[0]); (void)hipFree(s.vvalbuf[1]); (void)hipFree(s.depbuf[0]); (void)hipFree(s.depbuf[1]); (void)hipFree(s.v.ifc_in); (void)hipFree(s.v.ifc_code); (void)hipFree(s.v.ifc_list); (void)hipFree(s.v.ifc_n);
     }
     void* ccp[] = {h->d_cc_parent, h->d_cc_roots, h->d_cc_cid, h->d_cc_labels, h->d_cc_stats, h->d_cc_n};
     for (void* p : ccp) if (p) (void)hipFree(p);
@@ -1608,7 +1606,7 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
                                (int)h->slabs.size(), C, (const StepState*)h->d_ss, (const cetkmc_event*)(d_dom + D));
             n_touch = NE;
         }
-        hipLaunchKernelGGL(k_domain_touch, dim3((n_touch + 7) / 8), dim3(256), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
+        hipLaunchKernelGGL(k_domain_touch, dim3(2 * ((n_touch + 15) / 16)), dim3(256), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
                            (int)h->slabs.size(), n_touch, (const cetkmc_event*)d_dom, (const StepState*)h->d_ss, (const double*)h->d_ktab);
         hipLaunchKernelGGL(k_super_commit, dim3(1), dim3(64), 0, h->stream, h->d_ss, d_cnt, h->d_log_total, h->d_log_nev);
         h->swept = false;

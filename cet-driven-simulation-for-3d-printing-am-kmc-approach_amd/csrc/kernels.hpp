@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void k_sweep_simple(KParams P, SlabView S, con
 // census of all 8 is 17 LDS loads + OR / v_alignbyte on packed bytes -- no compares, no counters.
 //   TAB (variant 1, default): the per-voxel rate table vval is streamed (64 B per lane): an empty voxel's
 //     EMPTY-category sum / an atom's DIFF-category sum is the table entry, the census decides which voxels
-//     count (empty; atom with an empty neighbour) and which are interface voxels (event count from ifc_cnt).
+//     count (empty; atom with an empty neighbour) and which are interface voxels (event count in bits 7:2 of the class byte).
 //   !TAB (variant 2, "recompute"): T is streamed instead and the nucleation rate of every empty voxel without
 //     W/Re/C neighbours is evaluated in the sweep (Newton reciprocal + 14-FMA exp per voxel); interface voxels
 //     take their sums from vval.  Same bits as variant 1 (k_rate_table evaluates the same nuc_bulk()).
@@ -255,7 +255,6 @@ struct StreamArgs {
     const uint8_t* cls;
     const double* T;          // streamed by the recompute variant
     const double* vval;       // streamed by the table variant; gathered at interface voxels by the recompute variant
-    const uint8_t* ifc_cnt;
     const double* dep_val;    // plane L-1 deposition rates by temperature (SlabView::dep_val)
     double* rowsum;
     int32_t* rowcnt;
@@ -949,7 +948,7 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
                 const bool listed = ifc_ready && S.ifc_in[t] != 0;
                 maybe_ifc = (!ifc_ready || listed) ? 1 : 0;
                 const double v_tab = S.vval[t];
-                const int c_ifc = S.ifc_cnt[t];
+                const int c_ifc = S.cls[S.cidx(li, j, k)] >> 2;      // event count of a listed voxel (ifc_store)
                 if (ifc_ready) {
                     if (c == CAT_DEP) {
                         const double rate = S.dep_val[(int64_t)j * S.pitchT + k];
@@ -1037,7 +1036,7 @@ __global__ __launch_bounds__(256) void k_select(KParams P, const SlabView* __res
 // A voxel "owns interface events" iff it is empty with a W/Re/C neighbour (attachment) or a
 // W/Re/C atom with an empty neighbour (diffusion).  These are rare (a few per lattice row) and
 // expensive, so they are kept in a per-slab list (append-only superset, rebuilt at upload),
-// evaluated one voxel per lane by k_interface into vval/ifc_cnt, and merely
+// evaluated one voxel per lane by k_interface into vval / the class byte's count, and merely
 // looked up by the streaming sweep kernel.
 // Packed neighbourhood of a voxel: bits [2m+1:2m] describe neighbour slot m, bits [29:28] the voxel.
 //   empty voxel (own = 0): slot = species of a W/Re/C neighbour (1,2,3), 0 otherwise
@@ -1170,20 +1169,19 @@ __device__ __forceinline__ void ifc_eval_atom(const KParams& P, const SlabView& 
 }
 
 // result of a listed voxel's evaluation: table entry, event count, and the count mirrored into bits 7:2 of the voxel's
-// class byte (the sweep reads it there, from LDS, instead of gathering ifc_cnt); bits 1:0 = class8(state), which the
+// class byte (the sweep reads it there, from LDS, no separate count array); bits 1:0 = class8(state), which the
 // packed neighbourhood word carries (write_site keeps cls and state level), so the byte is written without being read
 __device__ __forceinline__ int code_state(unsigned code) { return (code >> 30) ? 4 : (int)((code >> 28) & 3u); }
 __device__ __forceinline__ void ifc_store(const SlabView& S, int li, int j, int k, int64_t t, double sum, int cnt, unsigned code)
 {
     S.vval[t] = sum;
-    S.ifc_cnt[t] = (uint8_t)cnt;
     S.cls[S.cidx(li, j, k)] = (uint8_t)(class8(code_state(code)) | ((unsigned)cnt << 2));
 }
 
 // after an event changed voxel (i,j,k): it and its 14 neighbours may have become interface voxels,
 // and the category sums of those already listed are stale (their neighbour states / orientations
 // changed).  Called by a full wave: lane l < 15 handles one of the 15 voxels: append if needed, then
-// re-evaluate if listed -- this keeps vval/ifc_cnt exact when k_interface ran BEFORE the event
+// re-evaluate if listed -- this keeps vval / the count exact when k_interface ran BEFORE the event
 // (the speculative, overlapped launch of the batched loop).
 // dedupe: the wave touches TWO neighbourhoods (a diffusion: site and target), so two lanes may hold the same voxel and
 // the list append needs the atomic test-and-set; otherwise the <= 15 voxels are distinct and the appends of the wave

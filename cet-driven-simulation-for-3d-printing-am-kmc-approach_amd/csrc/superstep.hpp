@@ -98,7 +98,7 @@ struct DomPick {          // the chosen event of one box, before the uniforms ar
 // The uniforms and the lattice write follow in k_domain_apply, one THREAD per box (fused into this kernel's lane 0 they
 // cost more: 32 768 waves each dragging a serial sincos / store tail, 97 vs 37 + 14 us).
 // The per-voxel rate table (SlabView::vval) holds the EMPTY- or
-// DIFF-category sum of EVERY owned voxel that owns events (listed voxels: interface sums + ifc_cnt; other empty voxels:
+// DIFF-category sum of EVERY owned voxel that owns events (listed voxels: interface sums + the count in the class byte; other empty voxels:
 // the nucleation rate by temperature), so a leaf is a few loads (dep leaves: one exp, top plane only).
 __global__ __launch_bounds__(64) void k_domain_pick(KParams P, const SlabView* __restrict__ slabs, int nslabs, int L,
                                                     SuperCfg C, const StepState* __restrict__ ss, const double* __restrict__ ktab_g,
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64) void k_domain_pick(KParams P, const SlabView* _
         const int64_t t = S.tidx(li, j, k);
         // value, count and membership flag are requested together with the state
         double val = S.vval[t];
-        int n_ev = S.ifc_cnt[t];
+        int n_ev = S.cls[S.cidx(li, j, k)] >> 2;
         const int listed = S.ifc_in[t] != 0;
         if (st >= 128 || st == 4) continue;
         if (!listed) {          // not an interface voxel: an empty voxel owns at most its nucleation (the table entry), an atom nothing
@@ -299,13 +299,15 @@ __global__ __launch_bounds__(256) CETKMC_TOUCH_ATTR void k_domain_touch(KParams 
     const int tid = threadIdx.x;
     if (tid < 225) ktab[tid] = ktab_g[tid];
     __syncthreads();
-    const int d = blockIdx.x * 8 + (tid >> 5), l = tid & 31;
-    if (d >= D || l == 15 || l == 31) return;
+    // 16 lanes per (event, half): the event's voxel and its 14 neighbours; the first grid half takes the events' own voxels,
+    // the second half the diffusion targets (whole waves of it leave at once where no event of theirs is a diffusion)
+    const int nb_first = (D + 15) / 16;
+    const bool second = (int)blockIdx.x >= nb_first;
+    const int d = ((int)blockIdx.x - (second ? nb_first : 0)) * 16 + (tid >> 4), m = tid & 15;
+    if (d >= D || m == 15) return;
     const cetkmc_event ev = dom_events[d];
-    const bool second = l >= 16;
     if (ev.type < 0 || (second && ev.type != EV_DIFF)) return;
     int ai = second ? ev.target[0] : ev.pos[0], aj = second ? ev.target[1] : ev.pos[1], ak = second ? ev.target[2] : ev.pos[2];
-    const int m = l & 15;
     if (m < 14) { ai += nbi_rt(m); aj += nbj_rt(m); ak += nbk_rt(m); }
     for (int s = 0; s < nslabs; ++s) {
         const SlabView& S = slabs[s];

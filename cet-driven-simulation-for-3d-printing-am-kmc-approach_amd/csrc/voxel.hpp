@@ -74,7 +74,6 @@ struct SlabView {
                         // count, kmc_event_rates.py:122-130), written by k_rate_table after every temperature change.
     double* dep_val;    // [L][pitchT] deposition rate of every (j,k) of plane L-1 from its T alone (kmc_event_rates.py:59-63;
                         // emptiness is tested by the reader); refreshed by k_rate_table; used iff the slab owns plane L-1
-    uint8_t* ifc_cnt;   // same indexing: event count of a LISTED voxel (others: vval != 0 ? 1 : 0 for an empty voxel)
     uint8_t* ifc_in;    // same indexing: 1 if the voxel is in ifc_list
     uint32_t* ifc_code; // same indexing: packed neighbourhood of a listed voxel (ifc_encode), kept current by apply
     uint32_t* ifc_list; // packed (lp << 20 | j << 10 | k) of the listed voxels (append-only, superset)
