@@ -190,8 +190,13 @@ def main():
     # ---- synthetic input, resident in HBM before anything is timed -----------------------
     a0, a1 = max(0, eng.i0 - 2), min(L, eng.i1 + 2)
     state, theta, phi, T, defects = synthetic.planes(L, a0, a1, seed=SEED)
+    eng.sync()
+    t_up = time.perf_counter()
     eng.upload_planes(a0, a1, state, theta, phi, T, defects)
     eng.set_prev_state(None)
+    eng.sync()
+    t_up = time.perf_counter() - t_up            # host -> HBM over PCIe (+ device-side packing); never part of `value`
+    upload_bytes = sum(x.nbytes for x in (state, theta, phi, T, defects))
 
     def prepare(step0, n):
         """Host-side inputs of a batch (random streams, laser source planes); built BEFORE timing."""
@@ -421,6 +426,23 @@ def main():
     mode_b = guarded("mode_b", do_mode_b) if (not a.no_mode_b and L % 8 == 0 and (L // N) % 8 == 0) else None
 
     ev_over_ms = guarded("event_overhead", lambda: eng.event_overhead(50))
+
+    # ---- what the boundary costs when it hands over host buffers: the lattice up before and down after a job
+    def do_pcie():
+        eng.sync()
+        t3 = time.perf_counter()
+        d = eng.download_planes(eng.i0, eng.i1, state=True, theta=True, phi=True, T=True, defects=True)
+        t_dn = time.perf_counter() - t3
+        dn_bytes = sum(x.nbytes for x in d.values())
+        job = 2000
+        return {"upload_ms": 1e3 * t_up, "upload_GBps": upload_bytes / t_up / 1e9, "download_ms": 1e3 * t_dn,
+                "download_GBps": dn_bytes / t_dn / 1e9, "bytes_up": int(upload_bytes), "bytes_down": int(dn_bytes),
+                "executed_events_per_s_timed_steps": a.steps / (dt + t_up + t_dn),
+                "executed_events_per_s_2000_step_job": job / (job * dt / a.steps + t_up + t_dn),
+                "note": "rank 0's slab (+halo on the way up) in the plane API's types (u8 state/defects, f64 theta/phi/T) from and to "
+                        "pageable NumPy arrays; the timed region itself starts with everything resident in HBM, so these rates "
+                        "are context, never `value`"}
+    pcie = guarded("pcie_inclusive", do_pcie)
     cand = float(np.sum(r["n_events"].astype(np.float64)))     # identical on every rank (global counts)
     steps_per_s = a.steps / dt
     sweep_ms = r["sweep_ms_total"] / max(r["sweep_launches"], 1)
@@ -509,6 +531,8 @@ def main():
                                  "ms_per_call": float(np.mean(refresh_ms)) if refresh_ms else None,
                                  "note": "gather of the carbon sites + host Bernoulli draws + sparse mask upload; inside the timed "
                                          "region whenever a timed step is a multiple of 200"}
+    if pcie is not None:
+        out["pcie_inclusive"] = pcie
     if phases is not None:
         out["phases"] = phases
     if recompute is not None:
