@@ -23,13 +23,13 @@ rs = np.random.RandomState(1)
 step, pos = 0, 0
 u_np = rs.random_sample(200000)
 e.set_option("reserve_batch", n)
-for staged in (False, True, False, True):
+for staged, prof in ((False, 1), (True, 1), (True, 0), (True, 3), (True, 1), (True, 0)):
     walls, devs = [], []
     for rep in range(12):
         u_pick, u_def = rs.random_sample(n), rs.random_sample(n)
         q = synthetic.laser_planes(L, step, n)
         args = (step, n, 3e-3, u_pick, u_def, u_np[pos:pos + 2 * n + 2])
-        kw = dict(rng_mode=1, seed=42, thermal_mode=2, q_planes=q, profile=1)
+        kw = dict(rng_mode=1, seed=42, thermal_mode=2, q_planes=q, profile=prof)
         if staged:
             e.stage_inputs(*args, **kw)
         e.sync()
@@ -42,4 +42,4 @@ for staged in (False, True, False, True):
         step += n
         pos += r["np_used"]
     w, d = np.median(walls[2:]), np.median(devs[2:])
-    print(f"staged={staged}: wall {w:.3f} ms, device {d:.3f} ms, host-side {w - d:.3f} ms per {n}-step batch -> {n / w * 1e3:.0f} steps/s", flush=True)
+    print(f"staged={staged} profile={prof}: wall {w:.3f} ms, device {d:.3f} ms, host-side {w - d:.3f} ms per {n}-step batch -> {n / w * 1e3:.0f} steps/s", flush=True)
