@@ -1593,8 +1593,12 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
         if (s > 0 && (!h->table_fresh || !h->ifc_fresh)) CHK(relist(h));
         CHK(launch_sweep(h, true, nullptr, nullptr, true));
         CHK(launch_select(h, cfg, 0.0, 1));                              // total, counts, termination test
-        hipLaunchKernelGGL(k_domain_pick, dim3(D), dim3(64), shmem, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
-                           (int)h->slabs.size(), h->L, C, (const StepState*)h->d_ss, (const double*)h->d_ktab, d_picks);
+        if (C.H == 4)       // box 8: window tree in registers
+            hipLaunchKernelGGL(k_domain_pick8, dim3(D), dim3(64), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
+                               (int)h->slabs.size(), h->L, C, (const StepState*)h->d_ss, (const double*)h->d_ktab, d_picks, (long long)s);
+        else
+            hipLaunchKernelGGL(k_domain_pick, dim3(D), dim3(64), shmem, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
+                               (int)h->slabs.size(), h->L, C, (const StepState*)h->d_ss, (const double*)h->d_ktab, d_picks);
         hipLaunchKernelGGL(k_domain_apply, dim3((D + 63) / 64), dim3(64), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
                            (int)h->slabs.size(), h->L, D, C, h->d_ss, (const DomPick*)d_picks, d_dom, d_cnt, d_log);
         int n_touch = D;

@@ -106,7 +106,11 @@ __global__ __launch_bounds__(64) void k_domain_pick(KParams P, const SlabView* _
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
-    const int dl = blockIdx.x, d = C.d0 + dl;   // local / global box index (the global one keys the uniforms)
+    // boxes that are neighbours along k share cache lines (a window row is 32 B of a 128-B line): consecutive boxes go to
+    // the same XCD (blocks are dealt round-robin over the 8 XCDs, each with its own L2)
+    int dl = blockIdx.x;
+    if ((gridDim.x & 7) == 0) dl = (dl & 7) * (int)(gridDim.x >> 3) + (dl >> 3);
+    const int d = C.d0 + dl;                    // local / global box index (the global one keys the uniforms)
     if (ss->status) return;
     const int NL = C.PT * C.PH * C.PH;
     double* hs = reinterpret_cast<double*>(smem);             // [2*NL]
@@ -209,6 +213,138 @@ __global__ __launch_bounds__(64) void k_domain_pick(KParams P, const SlabView* _
     if (lane == 0) picks[dl] = pk;
 }
 
+// The same pick for box = 8 (window 4 x 4 x 4, NL = 256 leaves) with the window tree in REGISTERS: lane = (block b = 3 ii + c,
+// row jj) owns the row's four leaves kk = 0..3 -- the canonical tree's first two levels fold inside the lane, the six above
+// by DPP / v_permlane*_swap with every level's block sum kept in the lane (as tree_select() does for Mode A), the descent
+// reads them back with v_readlane.  No LDS heap, no index divisions; the three category lanes of a row issue the same four
+// row loads (32 B of the table, one word each of state / class / membership).  Same leaves, pairs, descent rule and slot scan
+// as k_domain_pick (tests: Mode B parity against the oracle runs box 8 through this kernel, the other boxes through that one).
+__global__ __launch_bounds__(64) void k_domain_pick8(KParams P, const SlabView* __restrict__ slabs, int nslabs, int L,
+                                                     SuperCfg C, const StepState* __restrict__ ss, const double* __restrict__ ktab_g,
+                                                     DomPick* __restrict__ picks, long long cur_hint)
+{
+    const int lane = threadIdx.x;
+    int dl = blockIdx.x;
+    if ((gridDim.x & 7) == 0) dl = (dl & 7) * (int)(gridDim.x >> 3) + (dl >> 3);      // consecutive boxes on one XCD
+    const int d = C.d0 + dl;
+    // the batch status is only needed for the one store at the end (a terminated batch writes nothing; everything read
+    // on the way is valid memory either way), the super-step index comes from the host (== ss->cur while status == 0):
+    // no load stands between the launch and the window's loads
+    const int status = ss->status;
+    const int64_t g = C.step0 + cur_hint;
+    const int sec = (int)(g & 7);
+    const int nb = C.nb;
+    const int di = d / (nb * nb), dj = (d / nb) % nb, dk = d % nb;
+    const int i0 = di * 8 + ((sec >> 2) & 1) * 4, j0 = dj * 8 + ((sec >> 1) & 1) * 4, k0 = dk * 8 + (sec & 1) * 4;
+    const int b = lane >> 2, jj = lane & 3;
+    const int ii = (b * 11) >> 5, c = b - 3 * ii;            // b / 3, b % 3 for b < 16 (b >= 12: padding blocks, no leaves)
+    double lf[4] = {0.0, 0.0, 0.0, 0.0};
+    unsigned lcode = 0;                                       // byte kk: event count | 128 if the voxel is a listed interface voxel
+    if (b < 12) {
+        const int i = i0 + ii, j = j0 + jj;
+        int sl = 0;
+        for (int s = 1; s < nslabs; ++s) if (i >= slabs[s].gi0 && i < slabs[s].gi0 + slabs[s].nloc) sl = s;
+        const SlabView& S = slabs[sl];
+        const int li = i - S.gi0 + 2;
+        const int64_t t = S.tidx(li, j, k0);
+        // the row's four voxels: everything is requested together (k0 is a multiple of 4: the words are aligned)
+        const unsigned st4 = *reinterpret_cast<const unsigned*>(S.state + S.sidx(li, j, k0));
+        const unsigned cl4 = *reinterpret_cast<const unsigned*>(S.cls + S.cidx(li, j, k0));
+        const unsigned in4 = *reinterpret_cast<const unsigned*>(S.ifc_in + t);
+        const double2 va = *reinterpret_cast<const double2*>(S.vval + t), vb = *reinterpret_cast<const double2*>(S.vval + t + 2);
+        const double vv[4] = {va.x, va.y, vb.x, vb.y};
+        const bool top = (i == L - 1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int st = (st4 >> (8 * kk)) & 255u;
+            if (st >= 128 || st == 4) continue;
+            if (c == CAT_DEP) {
+                if (top && st == 0) {
+                    const double rate = dep_rate(P, pymax(S.T[t + kk], 1.0));
+                    if (finite_d(rate)) { lf[kk] = rate; lcode |= 1u << (8 * kk); }
+                }
+                continue;
+            }
+            const bool listed = ((in4 >> (8 * kk)) & 255u) != 0u;
+            double val = vv[kk];
+            int n_ev = (int)((cl4 >> (8 * kk + 2)) & 63u);
+            if (!listed) {      // an empty voxel owns at most its nucleation (the table entry), an atom nothing
+                if (st == 0) n_ev = (val != 0.0) ? 1 : 0;
+                else { val = 0.0; n_ev = 0; }
+            }
+            if (c == ((st == 0) ? CAT_EMPTY : CAT_DIFF)) { lf[kk] = val; lcode |= ((unsigned)n_ev | (listed ? 128u : 0u)) << (8 * kk); }
+        }
+    }
+    // "holds events" flags of the four leaves, then the tree
+    unsigned fm = 0u;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) if ((lcode >> (8 * kk)) & 127u) fm |= 1u << kk;
+    const double p0 = lf[0] + lf[1], p1 = lf[2] + lf[3];
+    double lv[7];
+    lv[0] = p0 + p1;
+    lv[1] = lv[0] + dpp_f64(lv[0], 0);
+    lv[2] = lv[1] + dpp_f64(lv[1], 1);
+    lv[3] = lv[2] + dpp_f64(lv[2], 2);
+    lv[4] = lv[3] + dpp_f64(lv[3], 3);
+    {
+        const unsigned lo = __double2loint(lv[4]), hi = __double2hiint(lv[4]);
+        const auto r0 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto r1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        lv[5] = __hiloint2double((int)r1[0], (int)r0[0]) + __hiloint2double((int)r1[1], (int)r0[1]);
+    }
+    {
+        const unsigned lo = __double2loint(lv[5]), hi = __double2hiint(lv[5]);
+        const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        lv[6] = __hiloint2double((int)r1[0], (int)r0[0]) + __hiloint2double((int)r1[1], (int)r0[1]);
+    }
+    const unsigned long long mask = __ballot(fm != 0u);
+    const double R = lv[6];
+    DomPick pk;
+    pk.i = 0; pk.j = 0; pk.k = 0; pk.type = -1; pk.m = -1; pk.atom = 0; pk.rate = 0.0;
+    if (mask != 0ull && !(R < 1e-25) && finite_d(R)) {       // wave-uniform
+        const double r = counter_uniform(C.seed, (uint64_t)g, KEY_PICK | (uint64_t)d) * R;
+        double base = 0.0;
+        int a = 0;
+#pragma unroll
+        for (int l = 5; l >= 0; --l) {          // go left iff the right half holds no events, or the left holds events and base + sum(left) >= r
+            const int hw = 1 << l;
+            const double sl = readlane_f64(lv[l], a);
+            const unsigned long long bits = (hw == 32) ? 0xFFFFFFFFull : ((1ull << hw) - 1ull);
+            const bool fl = ((mask >> a) & bits) != 0ull, fr = ((mask >> (a + hw)) & bits) != 0ull;
+            if (!(!fr || (fl && base + sl >= r))) { base += sl; a += hw; }
+        }
+        // inside the lane: every lane walks its own four leaves from the same base; the chosen lane's walk counts
+        double bl = base;
+        int hp;
+        if ((fm & 0xCu) == 0u || ((fm & 0x3u) != 0u && bl + p0 >= r)) hp = 0; else { bl += p0; hp = 1; }
+        const double ll = hp ? lf[2] : lf[0];
+        const unsigned f2 = (fm >> (2 * hp)) & 0x3u;
+        int hl;
+        if ((f2 & 0x2u) == 0u || ((f2 & 0x1u) != 0u && bl + ll >= r)) hl = 0; else { bl += ll; hl = 1; }
+        const int slot = 2 * hp + hl;
+        const double leaf = (slot == 0) ? lf[0] : (slot == 1) ? lf[1] : (slot == 2) ? lf[2] : lf[3];
+        const int code = (int)((lcode >> (8 * slot)) & 255u);
+        const int la = __builtin_amdgcn_readfirstlane(a);
+        const int kk_a = __builtin_amdgcn_readlane(slot, la), code_a = __builtin_amdgcn_readlane(code, la);
+        const double base_a = readlane_f64(bl, la), leaf_a = readlane_f64(leaf, la);
+        const int b_a = la >> 2, ii_a = (b_a * 11) >> 5, cat = b_a - 3 * ii_a;
+        pk.i = i0 + ii_a; pk.j = j0 + (la & 3); pk.k = k0 + kk_a;
+        if (code_a == 1 && cat != CAT_DIFF) {    // one event, voxel not listed (or a deposition leaf): nothing to scan
+            pk.type = (cat == CAT_DEP) ? EV_DEP : EV_NUC;
+            pk.atom = (cat == CAT_DEP) ? 0 : 1;
+            pk.rate = leaf_a;
+        } else {
+            int sl = 0;
+            for (int s = 1; s < nslabs; ++s) if (pk.i >= slabs[s].gi0 && pk.i < slabs[s].gi0 + slabs[s].nloc) sl = s;
+            const SlabView& S = slabs[sl];
+            const SlotPick sp = slot_scan_wave(P, S, ktab_g, pk.i - S.gi0 + 2, pk.j, pk.k, cat, base_a, r, lane);
+            pk.type = sp.type; pk.m = sp.m; pk.atom = sp.atom; pk.rate = sp.rate;
+        }
+    }
+    if (lane == 0 && !status) picks[dl] = pk;
+}
+
 // One thread per box: event record, uniforms, lattice write (kmc_simulation.py:276-327).  Reads stay within +-2 of the
 // chosen voxel and so do the writes of every other box's event (>= 5 away on some axis): no box reads what another writes.
 __global__ __launch_bounds__(64) void k_domain_apply(KParams P, const SlabView* __restrict__ slabs, int nslabs, int L, int D,
@@ -303,7 +439,9 @@ __global__ __launch_bounds__(256) CETKMC_TOUCH_ATTR void k_domain_touch(KParams 
     // the second half the diffusion targets (whole waves of it leave at once where no event of theirs is a diffusion)
     const int nb_first = (D + 15) / 16;
     const bool second = (int)blockIdx.x >= nb_first;
-    const int d = ((int)blockIdx.x - (second ? nb_first : 0)) * 16 + (tid >> 4), m = tid & 15;
+    int bh = (int)blockIdx.x - (second ? nb_first : 0);
+    if ((nb_first & 7) == 0) bh = (bh & 7) * (nb_first >> 3) + (bh >> 3);       // consecutive events on one XCD (shared lines)
+    const int d = bh * 16 + (tid >> 4), m = tid & 15;
     if (d >= D || m == 15) return;
     const cetkmc_event ev = dom_events[d];
     if (ev.type < 0 || (second && ev.type != EV_DIFF)) return;
