@@ -942,23 +942,26 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
             double sum = 0.0; int cnt = 0;
             int maybe_ifc = 1;      // 0: certainly no interface voxel (its EMPTY category can only hold a nucleation)
             if (k < L) {
-                // state, membership flag, table entry, count (and temperature) are requested together (one round trip)
                 const int64_t t = S.tidx(li, j, k);
-                const int st = S.state[S.sidx(li, j, k)];
-                const bool listed = ifc_ready && S.ifc_in[t] != 0;
-                maybe_ifc = (!ifc_ready || listed) ? 1 : 0;
-                const double v_tab = S.vval[t];
-                const int c_ifc = S.cls[S.cidx(li, j, k)] >> 2;      // event count of a listed voxel (ifc_store)
                 if (ifc_ready) {
+                    // table entry and class byte (one round trip): the byte says whether the voxel is empty (bit 0) and how
+                    // many events a LISTED voxel owns (bits 7:2, ifc_store(); zero for every voxel that is not listed --
+                    // and a listed voxel without events holds a zero table entry, so it reads like an unlisted one)
+                    const double v_tab = S.vval[t];
+                    const unsigned cb = S.cls[S.cidx(li, j, k)];
+                    const int c_ifc = (int)(cb >> 2);
+                    const bool empty = (cb & 1u) != 0u;
+                    maybe_ifc = c_ifc > 0 ? 1 : 0;
                     if (c == CAT_DEP) {
                         const double rate = S.dep_val[(int64_t)j * S.pitchT + k];
-                        if (st == 0 && finite_d(rate)) { sum = rate; cnt = 1; }
-                    } else if (listed) {
-                        if ((c == CAT_EMPTY) == (st == 0)) { sum = v_tab; cnt = c_ifc; }
-                    } else if (c == CAT_EMPTY && st == 0) {
-                        sum = v_tab; cnt = (v_tab != 0.0) ? 1 : 0;
+                        if (empty && finite_d(rate)) { sum = rate; cnt = 1; }
+                    } else if (c == CAT_EMPTY) {
+                        if (empty) { sum = v_tab; cnt = c_ifc > 0 ? c_ifc : ((v_tab != 0.0) ? 1 : 0); }
+                    } else if (!empty && c_ifc > 0) {
+                        sum = v_tab; cnt = c_ifc;
                     }
                 } else {
+                    const int st = S.state[S.sidx(li, j, k)];
                     const double Traw = S.T[t];
                     auto nb = [&](int mm) -> int { return S.state[S.sidx(li + nbi_rt(mm), j + nbj_rt(mm), k + nbk_rt(mm))]; };
                     auto emit = [&](int cat, int, double rate, int, int) { if (cat == c) { sum += rate; ++cnt; } };

@@ -131,21 +131,23 @@ __global__ __launch_bounds__(64) void k_domain_pick(KParams P, const SlabView* _
         for (int s = 0; s < nslabs; ++s) if (i >= slabs[s].gi0 && i < slabs[s].gi0 + slabs[s].nloc) sl = s;
         const SlabView& S = slabs[sl];
         const int li = i - S.gi0 + 2;
-        const int st = S.state[S.sidx(li, j, k)];
         const int64_t t = S.tidx(li, j, k);
-        // value, count and membership flag are requested together with the state
+        // table entry + class byte: bit 0 empty, bit 1 W/Re/C atom (neither: defect / outside), bits 7:2 the event count of a
+        // LISTED voxel (zero for every other voxel; a listed voxel without events holds a zero table entry)
         double val = S.vval[t];
-        int n_ev = S.cls[S.cidx(li, j, k)] >> 2;
-        const int listed = S.ifc_in[t] != 0;
-        if (st >= 128 || st == 4) continue;
-        if (!listed) {          // not an interface voxel: an empty voxel owns at most its nucleation (the table entry), an atom nothing
-            if (st == 0) n_ev = (val != 0.0) ? 1 : 0;
+        const unsigned cb = S.cls[S.cidx(li, j, k)];
+        if ((cb & 3u) == 0u) continue;
+        const bool empty = (cb & 1u) != 0u;
+        const int listed = (cb >> 2) != 0u;
+        int n_ev = (int)(cb >> 2);
+        if (!listed) {          // no interface events: an empty voxel owns at most its nucleation (the table entry), an atom nothing
+            if (empty) n_ev = (val != 0.0) ? 1 : 0;
             else { val = 0.0; n_ev = 0; }
         }
-        const int c = (st == 0) ? CAT_EMPTY : CAT_DIFF;
+        const int c = empty ? CAT_EMPTY : CAT_DIFF;
         const int q = ((3 * ii + c) * C.PH + jj) * C.PH + kk;
         hs[NL + q] = val; hf[NL + q] = n_ev > 0; lc[q] = (uint8_t)(n_ev | (listed << 7));
-        if (st == 0 && i == L - 1) {
+        if (empty && i == L - 1) {
             const double rate = dep_rate(P, pymax(S.T[t], 1.0));
             if (finite_d(rate)) {
                 const int qd = ((3 * ii + CAT_DEP) * C.PH + jj) * C.PH + kk;
@@ -216,8 +218,8 @@ __global__ __launch_bounds__(64) void k_domain_pick(KParams P, const SlabView* _
 // The same pick for box = 8 (window 4 x 4 x 4, NL = 256 leaves) with the window tree in REGISTERS: lane = (block b = 3 ii + c,
 // row jj) owns the row's four leaves kk = 0..3 -- the canonical tree's first two levels fold inside the lane, the six above
 // by DPP / v_permlane*_swap with every level's block sum kept in the lane (as tree_select() does for Mode A), the descent
-// reads them back with v_readlane.  No LDS heap, no index divisions; the three category lanes of a row issue the same four
-// row loads (32 B of the table, one word each of state / class / membership).  Same leaves, pairs, descent rule and slot scan
+// reads them back with v_readlane.  No LDS heap, no index divisions; the three category lanes of a row issue the same
+// row loads (32 B of the table, one word of class bytes).  Same leaves, pairs, descent rule and slot scan
 // as k_domain_pick (tests: Mode B parity against the oracle runs box 8 through this kernel, the other boxes through that one).
 __global__ __launch_bounds__(64) void k_domain_pick8(KParams P, const SlabView* __restrict__ slabs, int nslabs, int L,
                                                      SuperCfg C, const StepState* __restrict__ ss, const double* __restrict__ ktab_g,
@@ -248,31 +250,32 @@ __global__ __launch_bounds__(64) void k_domain_pick8(KParams P, const SlabView* 
         const int li = i - S.gi0 + 2;
         const int64_t t = S.tidx(li, j, k0);
         // the row's four voxels: everything is requested together (k0 is a multiple of 4: the words are aligned)
-        const unsigned st4 = *reinterpret_cast<const unsigned*>(S.state + S.sidx(li, j, k0));
         const unsigned cl4 = *reinterpret_cast<const unsigned*>(S.cls + S.cidx(li, j, k0));
-        const unsigned in4 = *reinterpret_cast<const unsigned*>(S.ifc_in + t);
         const double2 va = *reinterpret_cast<const double2*>(S.vval + t), vb = *reinterpret_cast<const double2*>(S.vval + t + 2);
         const double vv[4] = {va.x, va.y, vb.x, vb.y};
         const bool top = (i == L - 1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const int st = (st4 >> (8 * kk)) & 255u;
-            if (st >= 128 || st == 4) continue;
+            // class byte: bit 0 empty, bit 1 W/Re/C atom (neither: defect / outside), bits 7:2 the event count of a LISTED
+            // voxel (zero for every other voxel; a listed voxel without events holds a zero table entry)
+            const unsigned cb = (cl4 >> (8 * kk)) & 255u;
+            if ((cb & 3u) == 0u) continue;
+            const bool empty = (cb & 1u) != 0u;
             if (c == CAT_DEP) {
-                if (top && st == 0) {
+                if (top && empty) {
                     const double rate = dep_rate(P, pymax(S.T[t + kk], 1.0));
                     if (finite_d(rate)) { lf[kk] = rate; lcode |= 1u << (8 * kk); }
                 }
                 continue;
             }
-            const bool listed = ((in4 >> (8 * kk)) & 255u) != 0u;
+            const bool listed = (cb >> 2) != 0u;
             double val = vv[kk];
-            int n_ev = (int)((cl4 >> (8 * kk + 2)) & 63u);
+            int n_ev = (int)(cb >> 2);
             if (!listed) {      // an empty voxel owns at most its nucleation (the table entry), an atom nothing
-                if (st == 0) n_ev = (val != 0.0) ? 1 : 0;
+                if (empty) n_ev = (val != 0.0) ? 1 : 0;
                 else { val = 0.0; n_ev = 0; }
             }
-            if (c == ((st == 0) ? CAT_EMPTY : CAT_DIFF)) { lf[kk] = val; lcode |= ((unsigned)n_ev | (listed ? 128u : 0u)) << (8 * kk); }
+            if (c == (empty ? CAT_EMPTY : CAT_DIFF)) { lf[kk] = val; lcode |= ((unsigned)n_ev | (listed ? 128u : 0u)) << (8 * kk); }
         }
     }
     // "holds events" flags of the four leaves, then the tree
