@@ -454,14 +454,28 @@ def main():
     import re
     rounds = [(int(m.group(1)), f) for f in glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json"))
               for m in [re.fullmatch(r"r(\d+)_summary\.json", os.path.basename(f))] if m]
+    rocprof_kernels = None
     for _, summary_path in sorted(rounds, reverse=True):
         try:
-            kk = json.load(open(summary_path))["kernels"]["k_sweep_stream"]
+            allk = json.load(open(summary_path))["kernels"]
+            kk = allk["k_sweep_stream"]
             if N == 1 and L == 256 and "hbm_bytes_per_launch" in kk:
                 traffic, traffic_src, rocprof_ms = kk["hbm_bytes_per_launch"], os.path.relpath(summary_path, ROOT), kk["avg_us"] * 1e-3
+                rocprof_kernels = {k: round(allk[k]["avg_us"], 2) for k in ("k_sweep_stream", "k_plane_reduce", "k_select_apply",
+                                                                            "k_thermal_march", "k_rate_table", "k_interface",
+                                                                            "k_clear_row_flags") if k in allk and "avg_us" in allk[k]}
                 break
         except Exception:
             pass
+    if phases is not None and rocprof_kernels:
+        per_update = sum(rocprof_kernels.get(k, 0.0) for k in ("k_thermal_march", "k_rate_table", "k_interface", "k_clear_row_flags"))
+        phases["rocprof"] = {
+            "kernel_avg_us": rocprof_kernels, "source": traffic_src,
+            "select_apply_plus_reduce_plus_interface_us_per_step":
+                rocprof_kernels.get("k_select_apply", 0.0) + rocprof_kernels.get("k_plane_reduce", 0.0) + rocprof_kernels.get("k_interface", 0.0) / 20,
+            "per_update_work_us_per_step": per_update / 20,
+            "note": "the same loop in the committed rocprofv3 kernel trace (kernel durations without the hipEvent records: every "
+                    "phase boundary above carries one record, ~2 us); interface / thermal / table kernels run once per 20 steps"}
     workloads = {
         "config3": f"config 3: {L}^3 voxel lattice, one MI355X",
         "config4": f"config 4: the {L}^3 lattice of config 3 split into {N} axis-0 slabs, one rank per MI355X (strong scaling)",
