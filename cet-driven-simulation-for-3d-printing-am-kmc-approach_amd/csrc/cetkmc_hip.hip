@@ -135,6 +135,7 @@ struct Handle {
     int ifc_every_step = 0;    // 1: k_interface before every full sweep (round-1 behaviour, A/B); 0: only when stale --
                                // between temperature updates the apply kernel re-evaluates the <= 30 listed voxels an event touches
     int thermal_variant = 1;   // 1 = plane-marching LDS kernel, 0 = one thread per voxel
+    int thermal_general = 0;   // 1: k_thermal_march also where k_thermal_tiles applies (A/B, tests)
     int therm_ni = THERM_NI;   // planes per block of the marching kernel
     int ifc_blocks = 64;       // grid of k_interface (grid-stride over the device-side list length)
     int ifc_block = 256;
@@ -743,9 +744,17 @@ int launch_thermal(Handle* h, double dt, int laser, const double* d_q, int use_l
         SlabView v = view_of(h, (int)s);
         if (h->thermal_variant == 1) {
             dim3 grid((h->L + THERM_KT - 1) / THERM_KT, (h->L + THERM_TJ - 1) / THERM_TJ, (v.nloc + h->therm_ni - 1) / h->therm_ni);
-            hipLaunchKernelGGL(k_thermal_march, grid, dim3(256), 0, h->stream, v, (const double*)h->slabs[s].Tbuf[h->cur],
-                               h->slabs[s].Tbuf[nxt], h->slabs[s].prev, d_q, C,
-                               batch ? (const StepState*)h->d_ss : nullptr);
+            const StepState* ssp = batch ? (const StepState*)h->d_ss : nullptr;
+            const double* Tin = h->slabs[s].Tbuf[h->cur];
+            double* Tout = h->slabs[s].Tbuf[nxt];
+            uint8_t* prev = h->slabs[s].prev;
+            if (h->L % THERM_KT == 0 && h->L % THERM_TJ == 0 && !h->thermal_general) {      // the tiles cover the lattice exactly
+                if (laser && use_latent) hipLaunchKernelGGL((k_thermal_tiles<true, true>), grid, dim3(256), 0, h->stream, v, Tin, Tout, prev, d_q, C, ssp);
+                else if (laser) hipLaunchKernelGGL((k_thermal_tiles<true, false>), grid, dim3(256), 0, h->stream, v, Tin, Tout, prev, d_q, C, ssp);
+                else hipLaunchKernelGGL((k_thermal_tiles<false, false>), grid, dim3(256), 0, h->stream, v, Tin, Tout, prev, d_q, C, ssp);
+            } else {
+                hipLaunchKernelGGL(k_thermal_march, grid, dim3(256), 0, h->stream, v, Tin, Tout, prev, d_q, C, ssp);
+            }
         } else {
             dim3 grid((h->L + 255) / 256, h->L, v.nloc);
             hipLaunchKernelGGL(k_thermal, grid, dim3(256), 0, h->stream, v, (const double*)h->slabs[s].Tbuf[h->cur],
@@ -1047,7 +1056,11 @@ int cetkmc_set_option(void* handle, const char* key, int64_t value)
         return 0;
     }
     if (!strcmp(key, "thermal_variant")) {
-        if (value < 0 || value > 1) return fail("thermal_variant must be 0 (simple) or 1 (marching, default)");
+        // 0: one thread per voxel; 1 (default): plane marching -- k_thermal_tiles where the tiles cover the lattice exactly
+        // (L a multiple of 256), else k_thermal_march; 2: k_thermal_march everywhere
+        if (value < 0 || value > 2) return fail("thermal_variant must be 0 (simple), 1 (marching, default) or 2 (marching, general kernel only)");
+        h->thermal_general = value == 2 ? 1 : 0;
+        if (value == 2) value = 1;
         h->thermal_variant = (int)value;
         return 0;
     }

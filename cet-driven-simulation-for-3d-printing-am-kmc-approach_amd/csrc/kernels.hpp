@@ -1814,6 +1814,130 @@ __global__ __launch_bounds__(256) void k_thermal_march(SlabView S, const double*
     }
 }
 
+// k_thermal_tiles: k_thermal_march for lattices that the tiles cover exactly (L a multiple of THERM_TJ and of THERM_KT:
+// 256, 512, ...), with everything a partial tile needs taken out of the instruction stream: no per-voxel range tests, no
+// edge selects (the rim is loaded from clamped coordinates, which IS the edge replication: a tile edge is a lattice edge or
+// an interior boundary, never in between), row offsets computed once, the k-neighbours inside the thread's own column pair
+// taken from registers.  Same loads, same expression order, same bits (test_thermal_kernel_variants_identical).
+#ifndef CETKMC_THERM_ATTR
+#define CETKMC_THERM_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))   // latent-heat instantiation: 150 VGPRs otherwise (3 waves/SIMD); 40 B of scratch at 4
+#endif
+template <bool LASER, bool LATENT>
+__global__ __launch_bounds__(256) CETKMC_THERM_ATTR void k_thermal_tiles(SlabView S, const double* __restrict__ Tin, double* __restrict__ Tout,
+                                                       uint8_t* __restrict__ prev_state, const double* __restrict__ q_top,
+                                                       ThermalCfg C, const StepState* __restrict__ ss)
+{
+    constexpr int TJ = THERM_TJ, KT = THERM_KT, LW = KT + 2;
+    __shared__ double tile[(TJ + 2) * LW];
+    const int L = S.L, pitchT = S.pitchT;
+    const int tid = threadIdx.x;
+    const int kc = blockIdx.x * KT, j0 = blockIdx.y * TJ;
+    const int lp0 = blockIdx.z * C.ni, lp1 = min(lp0 + C.ni, S.nloc);
+    const int col = 2 * (tid & 127), rbase = tid >> 7;          // thread: columns kc+col, kc+col+1 of rows rbase+2q
+    const int k0 = kc + col;
+    const int64_t pstride = (int64_t)L * pitchT;
+    int off[4];                                                 // in-plane offsets of the thread's four column pairs
+#pragma unroll
+    for (int q = 0; q < 4; ++q) off[q] = (j0 + rbase + 2 * q) * pitchT + k0;
+    if (ss && ss->status) {                                     // terminated batch: the field is passed through unchanged
+        for (int lp = lp0; lp < lp1; ++lp)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t c = (int64_t)(lp + 2) * pstride + off[q];
+                *reinterpret_cast<double2*>(Tout + c) = *reinterpret_cast<const double2*>(Tin + c);
+            }
+        return;
+    }
+    const int scrub = C.scrub;
+    auto lplane = [&](int i) { return (i < 0 ? 0 : (i > L - 1 ? L - 1 : i)) - (S.gi0 - 2); };   // clamped global plane -> local
+    // rim cells of a plane: thread t loads (row j0-1, column kc+t) and (row j0+TJ, column kc+t); threads < 2 (TJ+2) the two
+    // side columns -- all from clamped coordinates
+    const int rim_top = max(j0 - 1, 0) * pitchT + kc + tid, rim_bot = min(j0 + TJ, L - 1) * pitchT + kc + tid;
+    const int side_row = tid >> 1, side_right = tid & 1;
+    const int side_off = min(max(j0 + side_row - 1, 0), L - 1) * pitchT + (side_right ? min(kc + KT, L - 1) : max(kc - 1, 0));
+    double prv[4][2], cur[4][2], nxt[4][2];
+    auto load_own = [&](int li, double (&dst)[4][2]) {
+        const double* base = Tin + (int64_t)li * pstride;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double2 v = *reinterpret_cast<const double2*>(base + off[q]);
+            dst[q][0] = scrub_T(v.x, C.T_nan, scrub);
+            dst[q][1] = scrub_T(v.y, C.T_nan, scrub);
+        }
+    };
+    load_own(lplane(S.gi0 + lp0 - 1), prv);
+    load_own(lp0 + 2, cur);
+    const double dtm = C.dt > 1e-12 ? C.dt : 1e-12;
+    const double dt_alpha = C.dt * C.alpha;
+#pragma unroll 1
+    for (int lp = lp0; lp < lp1; ++lp) {
+        const int li = lp + 2, i = S.gi0 + lp;
+        const double* plane = Tin + (int64_t)li * pstride;
+        // the rim is requested first, the next plane's own values behind it; plane i itself goes to LDS from registers
+        const double rt = plane[rim_top], rb = plane[rim_bot];
+        double rs = 0.0;
+        if (tid < 2 * (TJ + 2)) rs = plane[side_off];
+        load_own(lplane(i + 1), nxt);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double* row = tile + (rbase + 2 * q + 1) * LW + 1 + col;
+            row[0] = cur[q][0]; row[1] = cur[q][1];
+        }
+        tile[1 + tid] = scrub_T(rt, C.T_nan, scrub);
+        tile[(TJ + 1) * LW + 1 + tid] = scrub_T(rb, C.T_nan, scrub);
+        if (tid < 2 * (TJ + 2)) tile[side_row * LW + (side_right ? KT + 1 : 0)] = scrub_T(rs, C.T_nan, scrub);
+        __syncthreads();
+        const bool top = LASER && (i == L - 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = rbase + 2 * q, j = j0 + r;
+            unsigned st2 = 0, pv2 = 0;
+            if (LATENT && S.row_chg[(int64_t)li * L + j]) {      // wave-uniform (a wave's rows differ by q only)
+                const int64_t sc = S.sidx(li, j, k0);
+                st2 = *reinterpret_cast<const uint16_t*>(S.state + sc);
+                pv2 = *reinterpret_cast<const uint16_t*>(prev_state + sc);
+                *reinterpret_cast<uint16_t*>(prev_state + sc) = (uint16_t)st2;
+            }
+            const double* cell = tile + (r + 1) * LW + 1 + col;
+            const double jm0 = cell[-LW], jm1 = cell[-LW + 1], jp0 = cell[LW], jp1 = cell[LW + 1];
+            const double km0 = cell[-1], kp1 = cell[2];
+            double out[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const double tc = cur[q][h];
+                const double jm = h ? jm1 : jm0, jp = h ? jp1 : jp0;
+                const double km = h ? cur[q][0] : km0, kp = h ? kp1 : cur[q][1];
+                const double d0 = tc * -2.0 + (prv[q][h] + nxt[q][h]);
+                const double d1 = tc * -2.0 + (jm + jp);
+                const double d2 = tc * -2.0 + (km + kp);
+                const double lap = ((d0 + d1) + d2) * C.inv_dx2;
+                double nt;
+                if (!LASER) {
+                    nt = tc + dt_alpha * lap;
+                } else {
+                    // q/(rho cp) and dF/dt are zero for almost every voxel: 0/x is +0 exactly, so the two fp64 divisions are
+                    // only performed where the numerator is not zero (same bits as thermal_solver.py:99-103)
+                    double qterm = 0.0;
+                    if (top) {
+                        const double qv = q_top[(int64_t)j * L + k0 + h];
+                        qterm = (qv != 0.0) ? qv / C.rho_cp : 0.0;
+                    }
+                    double dF = 0.0;
+                    if (LATENT && ((pv2 >> (8 * h)) & 255u) == 0 && ((st2 >> (8 * h)) & 255u) != 0) dF = 1.0 / dtm;
+                    const double dTdt = C.alpha * lap + qterm + C.latent_coef * dF;
+                    nt = tc + C.dt * dTdt;
+                }
+                double v = nt < C.clip_lo ? C.clip_lo : nt;
+                out[h] = v > C.clip_hi ? C.clip_hi : v;
+            }
+            *reinterpret_cast<double2*>(Tout + (int64_t)li * pstride + off[q]) = make_double2(out[0], out[1]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { prv[q][0] = cur[q][0]; prv[q][1] = cur[q][1]; cur[q][0] = nxt[q][0]; cur[q][1] = nxt[q][1]; }
+    }
+}
+
 // ---- layout conversion -----------------------------------------------------------------------
 // src: contiguous (nplanes, L, L) covering global planes [i_begin, i_begin+nplanes)
 template <class SRC>

@@ -197,7 +197,9 @@ int cetkmc_sync(void* handle);
  * 2 = streaming kernel that recomputes the nucleation rates in every sweep; "interface_every_step" 1 = evaluate the
  * whole interface list before every full sweep instead of only after a temperature update; "thermal_lookahead" 1 = the next
  * temperature update of a batch and its rate table are computed ahead on a second stream (single process; same bits;
- * default 0: measured slower); "thermal_variant", "thermal_planes_per_block"; "reserve_batch" n = allocate the
+ * default 0: measured slower); "thermal_variant" 0 = one thread per voxel, 1 = plane marching (default:
+ * k_thermal_tiles where 8 x 256 tiles cover the lattice exactly, else k_thermal_march), 2 = k_thermal_march everywhere;
+ * "thermal_planes_per_block"; "reserve_batch" n = allocate the
  * device buffers and hipEvents of a batch of n steps now (a bench keeps hipMalloc / hipEventCreate out of its timed region) */
 int cetkmc_set_option(void* handle, const char* key, int64_t value);
 /* planes [*i0,*i1) owned by this handle (whole lattice unless created with create_rank) */

@@ -381,9 +381,11 @@ def test_config2_constant_T_128(oracle_mod):
         assert (got.type, tuple(got.pos), tuple(got.target)) == (want.type, tuple(want.pos), tuple(want.target)), u
 
 
-@pytest.mark.parametrize("L,n_slabs", [(5, 1), (19, 2), (64, 1), (130, 3), (300, 1)])
+@pytest.mark.parametrize("L,n_slabs", [(5, 1), (19, 2), (64, 1), (130, 3), (300, 1), (256, 1), (256, 4)])
 def test_thermal_kernel_variants_identical(L, n_slabs):
-    """Plane-marching LDS thermal kernel == one-thread-per-voxel kernel, bit for bit (cet + laser + latent)."""
+    """Plane-marching LDS thermal kernels (1: k_thermal_tiles where the tiles cover the lattice exactly -- L = 256 here --
+    else k_thermal_march; 2: k_thermal_march everywhere) == one-thread-per-voxel kernel, bit for bit (cet, laser with and
+    without the latent-heat term, NaN scrubbing)."""
     rs = np.random.RandomState(L)
     T = rs.uniform(2700.0, 4100.0, (L, L, L))
     T[rs.random_sample((L, L, L)) < 0.01] = np.nan
@@ -392,7 +394,7 @@ def test_thermal_kernel_variants_identical(L, n_slabs):
     q = rs.uniform(0, 1e15, (L, L))
     z = np.zeros((L, L, L))
     outs = []
-    for v in (0, 1):
+    for v in (0, 1, 2):
         e = _engine(L, n_slabs=n_slabs)
         e.set_option("thermal_variant", v)
         e.upload(state, z, z, T, state * 0)
@@ -402,9 +404,13 @@ def test_thermal_kernel_variants_identical(L, n_slabs):
         e.thermal_laser(1e-6, q, use_latent=True, scrub_nan=False)
         b = e.download()["T"]
         e.thermal_cet(3e-7, scrub_nan=False)
-        outs.append((a, b, e.download()["T"]))
-    for x, y in zip(*outs):
-        assert np.array_equal(x, y)
+        c = e.download()["T"]
+        e.thermal_laser(2e-6, q, use_latent=False, scrub_nan=True)
+        outs.append((a, b, c, e.download()["T"]))
+        e.close()
+    for o in outs[1:]:
+        for x, y in zip(outs[0], o):
+            assert np.array_equal(x, y)
 
 
 @pytest.mark.parametrize("L", [264, 344])
