@@ -563,10 +563,12 @@ __global__ __launch_bounds__(256) CETKMC_SWEEP_ATTR void k_sweep_stream(StreamAr
         int so[5];
 #pragma unroll
         for (int d = 0; d < 5; ++d) so[d] = ((li - 2 + d) % STREAM_SLOTS) * slab;
-        fetch_slab(li + 3);                  // next plane's new slab (a clamped dummy after the last plane): requested first,
-                                             // stored at the end of this plane while the value loads are still in flight
+        // next plane's new slab: requested first, stored at the end of this plane while the value loads are still in flight.
+        // After the block's last plane the (unconditional) requests go to what the block has just read -- its last slab, its
+        // last plane's values: cache hits, not another block's data dragged across the fabric for nothing
+        fetch_slab(min(li + 3, lp1 + 3));
         if (NP == 1) {
-            load_vals<TAB, HW>(A, min(li + 1, A.nloc + 1), j0 + row_of(0), lane, 0, nxt);
+            load_vals<TAB, HW>(A, min(li + 1, lp1 + 1), j0 + row_of(0), lane, 0, nxt);
             const int r = row_of(0);
             auto rowp = [&](int d, int dj) { return (const uint8_t*)smem + so[d + 2] + (r + 2 + dj) * pitchC + KOFFC; };
             sweep_row<TAB, HW, CH2>(A, rowp, li, lp, j0 + r, top, lane, cur);
@@ -578,7 +580,7 @@ __global__ __launch_bounds__(256) CETKMC_SWEEP_ATTR void k_sweep_stream(StreamAr
                 sweep_row<TAB, HW, CH2>(A, rowp, li, lp, j0 + r, top, lane, cur);
             }
             {
-                load_vals<TAB, HW>(A, min(li + 1, A.nloc + 1), j0 + row_of(0), lane, 0, cur);
+                load_vals<TAB, HW>(A, min(li + 1, lp1 + 1), j0 + row_of(0), lane, 0, cur);
                 const int r = row_of(1);
                 auto rowp = [&](int d, int dj) { return (const uint8_t*)smem + so[d + 2] + (r + 2 + dj) * pitchC + KOFFC; };
                 sweep_row<TAB, HW, CH2>(A, rowp, li, lp, j0 + r, top, lane, nxt);
