@@ -4,7 +4,7 @@
    (per-kernel average duration + HBM traffic from the FETCH_SIZE / WRITE_SIZE PMC passes).
 HBM traffic per launch = 2*FETCH_SIZE + WRITE_SIZE (KB -> bytes): on gfx950 FETCH_SIZE reports half
 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section); the x2 is applied to the
-streaming kernels (k_sweep_stream, k_rate_table, k_thermal: 16-B-per-lane loads) and NOT to the narrow-gather
+streaming kernels (k_sweep_stream, k_rate_table, k_thermal*: 16-B-per-lane loads) and NOT to the narrow-gather
 kernels, whose calibration is unknown (reported raw, flagged).  FETCH_SIZE counts the L2's memory-side requests:
 Infinity-Cache hits are included, so it is fabric traffic, an upper bound of what reaches HBM."""
 import collections
@@ -59,7 +59,7 @@ for which in ("fetch", "write"):
         summary["kernels"].setdefault(name, {})[f"{which}_size_kb_median"] = statistics.median(v)
 for name, k in summary["kernels"].items():
     if "fetch_size_kb_median" in k and "write_size_kb_median" in k:
-        wide = name in ("k_sweep_stream", "k_sweep_stream_recompute", "k_rate_table", "k_thermal", "k_thermal_march")
+        wide = name in ("k_sweep_stream", "k_sweep_stream_recompute", "k_rate_table", "k_thermal", "k_thermal_march", "k_thermal_tiles")
         k["hbm_bytes_per_launch"] = (2.0 if wide else 1.0) * k["fetch_size_kb_median"] * 1024 + k["write_size_kb_median"] * 1024
         k["fetch_x2_applied"] = wide
 modes = one(f"{tag}_stats_modes/*/*kernel_stats.csv")
