@@ -292,7 +292,9 @@ def main():
         r = run(step, a.warmup)
         step += r["done"]
     timed_inputs = prepare(step, a.steps)
-    # short runs (the driver's 20 steps): hipEvents around EVERY sweep launch; long runs: every 8th (a record costs ~5 us)
+    # short runs (the driver's 20 steps): a hipEvent pair on EVERY sweep launch; long runs: every 8th.  The pair rides on the
+    # launch (hipExtLaunchKernelGGL start / stop events: the dispatch's own timestamps, on the engine's stream), which still
+    # costs the timed loop ~4 us per timed launch
     prof_mode = 1 if a.steps <= 64 else 3
     eng.set_option("reserve_batch", a.steps)       # batch buffers / hipEvents: hipMalloc and hipEventCreate stay out of the timed region
     inputs_staged = stage(timed_inputs, profile=prof_mode)
@@ -510,9 +512,11 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "traffic_measured_in_run": False,
                      "avg_launch_ms": sweep_ms, "launches_timed": int(r["sweep_launches"]),
-                     # what the two hipEvent records themselves add to a bracketed launch (measured in this run around an
-                     # empty kernel); `frac` above is NOT corrected for it (conservative)
-                     "event_pair_overhead_ms": ev_over_ms,       # two records around an EMPTY kernel (its ~2-3 us included)
+                     "timing": "hipEvent pairs attached to the sweep launches of the timed region (hipExtLaunchKernelGGL start / "
+                               "stop events on the engine's stream; several slabs per process: hipEventRecord around the launches)",
+                     # what two hipEventRecord calls add around a launch (measured in this run around an empty kernel): the
+                     # phase table's boundaries and multi-slab handles are timed that way, the sweep launches above are not
+                     "event_pair_overhead_ms": ev_over_ms,       # two records around an EMPTY kernel (its ~3.5 us included)
                      "rocprof_avg_launch_ms": rocprof_ms,        # committed kernel trace of the same command (traffic_source)
                      "frac_rocprof": (B_ALG_SWEEP * n_own / (rocprof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if rocprof_ms else None,
                      "launches_in_timed_region": int(r["full_sweeps"]),
