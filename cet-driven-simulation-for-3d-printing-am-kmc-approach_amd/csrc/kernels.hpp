@@ -1869,16 +1869,24 @@ __global__ __launch_bounds__(256) CETKMC_THERM_ATTR void k_thermal_tiles(SlabVie
     };
     load_own(lplane(S.gi0 + lp0 - 1), prv);
     load_own(lp0 + 2, cur);
+    // rim of the first plane; every later plane's rim is requested one plane ahead, like its own values
+    double rt, rb, rs = 0.0;
+    {
+        const double* plane = Tin + (int64_t)(lp0 + 2) * pstride;
+        rt = plane[rim_top]; rb = plane[rim_bot];
+        if (tid < 2 * (TJ + 2)) rs = plane[side_off];
+    }
     const double dtm = C.dt > 1e-12 ? C.dt : 1e-12;
     const double dt_alpha = C.dt * C.alpha;
 #pragma unroll 1
     for (int lp = lp0; lp < lp1; ++lp) {
         const int li = lp + 2, i = S.gi0 + lp;
-        const double* plane = Tin + (int64_t)li * pstride;
-        // the rim is requested first, the next plane's own values behind it; plane i itself goes to LDS from registers
-        const double rt = plane[rim_top], rb = plane[rim_bot];
-        double rs = 0.0;
-        if (tid < 2 * (TJ + 2)) rs = plane[side_off];
+        // next plane's rim (after the block's last plane: the same plane again, cache hits) and own values are requested
+        // now and used in the next iteration; plane i itself goes to LDS from registers
+        const double* plane_n = Tin + (int64_t)min(li + 1, lp1 + 1) * pstride;
+        const double rt_n = plane_n[rim_top], rb_n = plane_n[rim_bot];
+        double rs_n = 0.0;
+        if (tid < 2 * (TJ + 2)) rs_n = plane_n[side_off];
         load_own(lplane(i + 1), nxt);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -1937,6 +1945,7 @@ __global__ __launch_bounds__(256) CETKMC_THERM_ATTR void k_thermal_tiles(SlabVie
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 4; ++q) { prv[q][0] = cur[q][0]; prv[q][1] = cur[q][1]; cur[q][0] = nxt[q][0]; cur[q][1] = nxt[q][1]; }
+        rt = rt_n; rb = rb_n; rs = rs_n;
     }
 }
 

@@ -15,7 +15,7 @@ for r in csv.DictReader(open(f)):
     if r["Counter_Name"] == "SQ_WAVES": calls[k] += 1
 for k in sorted(acc, key=lambda k: -acc[k]["SQ_WAVE_CYCLES"]):
     n = calls[k]
-    if n < 30: continue
+    if n < 10: continue
     a = acc[k]; w = a["SQ_WAVES"] / n
     print(f"{k:42s} waves {w:8.0f}  per wave: valu {a['SQ_INSTS_VALU']/a['SQ_WAVES']:7.0f} salu {a['SQ_INSTS_SALU']/a['SQ_WAVES']:6.0f} "
           f"vmem_rd {a['SQ_INSTS_VMEM_RD']/a['SQ_WAVES']:5.0f} vmem_wr {a['SQ_INSTS_VMEM_WR']/a['SQ_WAVES']:5.0f}  "
