@@ -1047,6 +1047,7 @@ int cetkmc_set_option(void* handle, const char* key, int64_t value)
         // batch of `value` steps, allocated ahead of it: a bench keeps hipMalloc / hipEventCreate out of its timed region
         if (value < 0 || value > (1 << 22)) return fail("reserve_batch out of range");
         HIPCHK(hipSetDevice(h->dev));
+        h->staged.valid = false;           // growing a buffer moves it: a batch staged before this call is gone
         const size_t n = (size_t)value;
         size_t c1 = h->cap_steps, c2 = h->cap_steps, c3 = h->cap_steps, c4 = h->cap_steps, c5 = h->cap_steps;
         CHK(grow(&h->d_u_pick, &c1, n));
