@@ -525,7 +525,11 @@ def main():
                      # theta + phi f64 + defects u8 streamed every sweep, thermal 16 B / 20) x steps/s.  The build does
                      # NOT stream theta/phi/defects (touched at interface voxels only), so this over-counts moved bytes;
                      # shown only because BASELINE.md's 40 % target (7.1 k steps/s at 256^3) is phrased in it.
-                     "baseline_md_accounting": {"bytes_per_voxel_step": 26.8,
+                     "baseline_md_accounting": {"note": "SURVEY 8(d)'s pre-build byte count (state + T + theta + phi + defects streamed every "
+                                                        "sweep) x steps/s; the build does not stream theta / phi / defects, so this counts "
+                                                        "bytes that are not moved -- shown only because BASELINE.md's 40 % target is phrased "
+                                                        "in it; `frac` above is the figure of merit",
+                                                "bytes_per_voxel_step": 26.8,
                                                 "achieved": 26.8 * float(L) ** 3 * steps_per_s / 1e9, "unit": "GB/s",
                                                 "frac": 26.8 * float(L) ** 3 * steps_per_s / 1e9 / HBM_PEAK_GBS}},
     }
