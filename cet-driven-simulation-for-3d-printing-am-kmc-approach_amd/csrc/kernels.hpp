@@ -55,14 +55,16 @@ constexpr int PMAX = 2048;         // max leaves of an LDS heap tree (3L <= PMAX
 // Balanced binary tree over the 64 lanes, result in every lane.  Levels 1,2 use quad_perm DPP,
 // levels 4,8 row_half_mirror / row_mirror DPP (the partner lane holds the sibling subtree's sum),
 // levels 16,32 the gfx950 v_permlane16_swap / v_permlane32_swap -- no LDS round trips.
+// (update_dpp with bound_ctrl and old = src: every lane of these permutations has a valid source, so the result never
+// depends on `old` and the compiler does not have to zero a register pair in front of every v_mov_b32_dpp)
 __device__ __forceinline__ double dpp_f64(double v, int ctrl_sel)
 {
     const unsigned lo = __double2loint(v), hi = __double2hiint(v);
     unsigned a, b;
-    if (ctrl_sel == 0) { a = __builtin_amdgcn_update_dpp(0u, lo, 0xB1, 0xF, 0xF, false); b = __builtin_amdgcn_update_dpp(0u, hi, 0xB1, 0xF, 0xF, false); }
-    else if (ctrl_sel == 1) { a = __builtin_amdgcn_update_dpp(0u, lo, 0x4E, 0xF, 0xF, false); b = __builtin_amdgcn_update_dpp(0u, hi, 0x4E, 0xF, 0xF, false); }
-    else if (ctrl_sel == 2) { a = __builtin_amdgcn_update_dpp(0u, lo, 0x141, 0xF, 0xF, false); b = __builtin_amdgcn_update_dpp(0u, hi, 0x141, 0xF, 0xF, false); }
-    else { a = __builtin_amdgcn_update_dpp(0u, lo, 0x140, 0xF, 0xF, false); b = __builtin_amdgcn_update_dpp(0u, hi, 0x140, 0xF, 0xF, false); }
+    if (ctrl_sel == 0) { a = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, true); b = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, true); }
+    else if (ctrl_sel == 1) { a = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, true); b = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, true); }
+    else if (ctrl_sel == 2) { a = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, 0xF, true); b = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, 0xF, true); }
+    else { a = __builtin_amdgcn_update_dpp(lo, lo, 0x140, 0xF, 0xF, true); b = __builtin_amdgcn_update_dpp(hi, hi, 0x140, 0xF, 0xF, true); }
     return __hiloint2double((int)b, (int)a);
 }
 __device__ __forceinline__ double wave_tree_sum(double v)
@@ -87,10 +89,10 @@ __device__ __forceinline__ double wave_tree_sum(double v)
 }
 __device__ __forceinline__ int wave_sum_i(int v)
 {
-    v += (int)__builtin_amdgcn_update_dpp(0u, (unsigned)v, 0xB1, 0xF, 0xF, false);
-    v += (int)__builtin_amdgcn_update_dpp(0u, (unsigned)v, 0x4E, 0xF, 0xF, false);
-    v += (int)__builtin_amdgcn_update_dpp(0u, (unsigned)v, 0x141, 0xF, 0xF, false);
-    v += (int)__builtin_amdgcn_update_dpp(0u, (unsigned)v, 0x140, 0xF, 0xF, false);
+    v += (int)__builtin_amdgcn_update_dpp((unsigned)v, (unsigned)v, 0xB1, 0xF, 0xF, true);
+    v += (int)__builtin_amdgcn_update_dpp((unsigned)v, (unsigned)v, 0x4E, 0xF, 0xF, true);
+    v += (int)__builtin_amdgcn_update_dpp((unsigned)v, (unsigned)v, 0x141, 0xF, 0xF, true);
+    v += (int)__builtin_amdgcn_update_dpp((unsigned)v, (unsigned)v, 0x140, 0xF, 0xF, true);
     { const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false); v = (int)(r[0] + r[1]); }
     { const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false); v = (int)(r[0] + r[1]); }
     return v;
@@ -301,10 +303,10 @@ __device__ __forceinline__ double wave_tree_sum_h(double v)
 template <bool HALF>
 __device__ __forceinline__ int wave_sum_i_h(int v)
 {
-    v += (int)__builtin_amdgcn_update_dpp(0u, (unsigned)v, 0xB1, 0xF, 0xF, false);
-    v += (int)__builtin_amdgcn_update_dpp(0u, (unsigned)v, 0x4E, 0xF, 0xF, false);
-    v += (int)__builtin_amdgcn_update_dpp(0u, (unsigned)v, 0x141, 0xF, 0xF, false);
-    v += (int)__builtin_amdgcn_update_dpp(0u, (unsigned)v, 0x140, 0xF, 0xF, false);
+    v += (int)__builtin_amdgcn_update_dpp((unsigned)v, (unsigned)v, 0xB1, 0xF, 0xF, true);
+    v += (int)__builtin_amdgcn_update_dpp((unsigned)v, (unsigned)v, 0x4E, 0xF, 0xF, true);
+    v += (int)__builtin_amdgcn_update_dpp((unsigned)v, (unsigned)v, 0x141, 0xF, 0xF, true);
+    v += (int)__builtin_amdgcn_update_dpp((unsigned)v, (unsigned)v, 0x140, 0xF, 0xF, true);
     { const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false); v = (int)(r[0] + r[1]); }
     if (!HALF) { const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false); v = (int)(r[0] + r[1]); }
     return v;
