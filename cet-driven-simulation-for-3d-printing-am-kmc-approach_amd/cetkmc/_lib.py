@@ -56,7 +56,7 @@ class SuperArgs(C.Structure):
     _fields_ = [
         ("step0", C.c_int64), ("n_steps", C.c_int64), ("box", C.c_int32), ("defect_fraction", C.c_double),
         ("seed", C.c_uint64), ("thermal_mode", C.c_int32), ("thermal_dt", C.c_double),
-        ("q_planes", C.POINTER(C.c_double)), ("n_q", C.c_int64), ("use_latent", C.c_int32),
+        ("q_planes", C.POINTER(C.c_double)), ("n_q", C.c_int64), ("use_latent", C.c_int32), ("null_events", C.c_int32),
     ]
 
 
@@ -118,7 +118,7 @@ PROTOTYPES = {
     "cetkmc_row_sums": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cetkmc_run_steps": (C.c_int, [C.c_void_p, _P(RunArgs), _P(RunResult), C.c_void_p, C.c_void_p, C.c_void_p]),
     "cetkmc_stage_inputs": (C.c_int, [C.c_void_p, _P(RunArgs)]),
-    "cetkmc_run_supersteps": (C.c_int, [C.c_void_p, _P(SuperArgs), _P(RunResult), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cetkmc_run_supersteps": (C.c_int, [C.c_void_p, _P(SuperArgs), _P(RunResult), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cetkmc_get_counters": (C.c_int, [C.c_void_p, _P(Counters), C.c_int]),
     "cetkmc_cluster": (C.c_int, [C.c_void_p, C.c_double, _P(C.c_int64)]),
     "cetkmc_cluster_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -174,12 +174,30 @@ def build_library(force=False, verbose=False):
     if not force and library_hash() == want:
         LAST_BUILD = "reused"
         return SO_PATH
-    LAST_BUILD = "compiled"
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + [f'-DCETKMC_SRC_HASH="{want}"', os.path.join(CSRC, "cetkmc_hip.hip"), "-o", SO_PATH, "-ldl"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
+    import fcntl
+    # several processes may import at once (torchrun ranks, the multi-process tests): one compiles, the others wait for the
+    # lock and then find the finished library; hipcc writes a temporary file that is renamed into place, so a concurrent
+    # dlopen never sees a half-written library
+    with open(SO_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and library_hash() == want:
+                LAST_BUILD = "reused"
+                return SO_PATH
+            LAST_BUILD = "compiled"
+            hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+            tmp = f"{SO_PATH}.tmp.{os.getpid()}"
+            cmd = [hipcc] + HIPCC_FLAGS + [f'-DCETKMC_SRC_HASH="{want}"', os.path.join(CSRC, "cetkmc_hip.hip"), "-o", tmp, "-ldl"]
+            if verbose:
+                print(" ".join(cmd))
+            try:
+                subprocess.check_call(cmd, cwd=CSRC)
+                os.replace(tmp, SO_PATH)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return SO_PATH
 
 

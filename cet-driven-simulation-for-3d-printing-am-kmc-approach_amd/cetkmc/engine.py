@@ -244,9 +244,9 @@ class Engine:
     def _run_args(self, step0, n, defect_fraction, u_pick, u_defect, u_np, rng_mode, seed, thermal_mode, thermal_dt, q_planes,
                   use_latent, profile, incremental):
         a = RunArgs()
-        u_pick = np.ascontiguousarray(u_pick, dtype=np.float64)
+        u_pick = None if u_pick is None else np.ascontiguousarray(u_pick, dtype=np.float64)     # rng_mode 2: no host streams
         u_defect = None if u_defect is None else np.ascontiguousarray(u_defect, dtype=np.float64)
-        u_np = np.ascontiguousarray(u_np, dtype=np.float64)
+        u_np = np.zeros(0) if u_np is None else np.ascontiguousarray(u_np, dtype=np.float64)
         q = None if q_planes is None else np.ascontiguousarray(q_planes, dtype=np.float64)
         a.step0, a.n_steps, a.defect_fraction = int(step0), int(n), float(defect_fraction)
         a.u_pick, a.u_defect, a.u_np = _dptr(u_pick), _dptr(u_defect), _dptr(u_np)
@@ -292,12 +292,17 @@ class Engine:
 
     # -- Mode B: synchronous super-steps over (L/box)^3 boxes (not in the reference; include/cetkmc.h) --------
     def run_supersteps(self, step0, n, box, defect_fraction, seed, thermal_mode=1, thermal_dt=1e-6, q_planes=None,
-                       use_latent=True, want_events=False):
+                       use_latent=True, want_events=False, null_events=False):
+        """box == L: the single-domain case (one Mode A step per super-step, counter uniforms of box 0).
+        Returns also ``dt_event`` (time increment per executed event of every super-step, kmc_simulation.py:331-332
+        restated; identical on every rank) -- simulated time advances by ``n_exec[g] * dt_event[g]`` with n_exec summed
+        over ranks."""
         a = SuperArgs()
         q = None if q_planes is None else np.ascontiguousarray(q_planes, dtype=np.float64)
         a.step0, a.n_steps, a.box, a.defect_fraction, a.seed = int(step0), int(n), int(box), float(defect_fraction), int(seed)
         a.thermal_mode, a.thermal_dt = int(thermal_mode), float(thermal_dt)
         a.q_planes, a.n_q, a.use_latent = _dptr(q), (0 if q is None else q.shape[0]), int(bool(use_latent))
+        a.null_events = int(bool(null_events))
         # boxes of this handle: the box layers of its owned planes (across ranks every rank runs its own boxes and logs
         # their events / executed counts; global box order = rank order)
         nbx = self.L // int(box) if box and self.L % int(box) == 0 else 1
@@ -305,12 +310,14 @@ class Engine:
         res = RunResult()
         totals = np.zeros(n + 1, np.float64)
         n_exec = np.zeros(max(n, 1), np.int64)
+        dt_event = np.zeros(max(n, 1), np.float64)
         events = np.zeros((max(n, 1), D), dtype=EVENT_DTYPE) if want_events else None
-        self._ck(self.lib.cetkmc_run_supersteps(self.h, C.byref(a), C.byref(res), _ptr(totals), _ptr(events), _ptr(n_exec)))
+        self._ck(self.lib.cetkmc_run_supersteps(self.h, C.byref(a), C.byref(res), _ptr(totals), _ptr(events), _ptr(n_exec),
+                                                _ptr(dt_event)))
         done = int(res.steps_done)
         return dict(done=done, status=int(res.status), q_used=int(res.q_used), nucleation_count=int(res.nucleation_count),
                     wall_ms=res.wall_ms, totals=totals[:done + (1 if res.status == 1 else 0)], n_exec=n_exec[:done],
-                    events=None if events is None else events[:done], domains=D)
+                    events=None if events is None else events[:done], domains=D, dt_event=dt_event[:done])
 
     # -- grain clustering (utils.get_clusters on the device) --------------------------------------
     def clusters(self, threshold=0.5, labels=False):

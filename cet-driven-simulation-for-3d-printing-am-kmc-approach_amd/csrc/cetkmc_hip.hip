@@ -12,6 +12,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdint>
+#include <climits>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -158,6 +160,10 @@ struct Handle {
         double dt = 0.0;
         const double* d_q = nullptr;
     } spec;
+    // A batch that stops with status 2 (stream exhausted) ON a temperature-update step has already applied that step's update
+    // (the thermal kernels run before the selection notices the shortage).  The continuation batch starts at the same
+    // global step: it must not apply the update a second time (kmc_simulation.py:248-250 updates T once per 20 steps).
+    int64_t therm_applied_g = -1;
     int thermal_ahead = 0;       // option "thermal_lookahead": off by default -- measured slower on one GPU:
                                  // the look-ahead kernels run right behind the update, beside the next sweeps, which they slow down
                                  // by more than the update costs (both are memory bound, and they evict the sweep's working set)
@@ -461,6 +467,7 @@ int upload_impl(Handle* h, int i_begin, int i_end, const I* state, const double*
     h->swept = false;
     if (T) h->table_fresh = false;
     h->ifc_fresh = false;
+    h->therm_applied_g = -1;
     return 0;
 }
 template <class I>
@@ -784,6 +791,7 @@ int launch_thermal(Handle* h, double dt, int laser, const double* d_q, int use_l
     h->cur = nxt;
     h->swept = false;
     h->table_fresh = false;
+    h->therm_applied_g = -1;
     return 0;
 }
 
@@ -1294,9 +1302,11 @@ static int check_run_args(Handle* h, const cetkmc_run_args* a, bool need_ptrs, i
 {
     const int64_t n = a->n_steps;
     if (n < 0) return fail("n_steps < 0");
-    if (need_ptrs && n > 0 && !a->u_pick) return fail("u_pick required");
-    if (need_ptrs && a->defect_fraction > 0.0 && n > 0 && !a->u_defect) return fail("u_defect required when defect_fraction > 0");
-    if (need_ptrs && a->np_cap > 0 && !a->u_np) return fail("u_np required");
+    if (a->rng_mode < 0 || a->rng_mode > 2) return fail("rng_mode must be 0 (reference stream), 1 (counter species draw) or 2 (all counter based)");
+    const bool streams = a->rng_mode != 2;          // rng_mode 2 draws every uniform from (seed, step, key): no host streams
+    if (need_ptrs && streams && n > 0 && !a->u_pick) return fail("u_pick required");
+    if (need_ptrs && streams && a->defect_fraction > 0.0 && n > 0 && !a->u_defect) return fail("u_defect required when defect_fraction > 0");
+    if (need_ptrs && streams && a->np_cap > 0 && !a->u_np) return fail("u_np required");
     int64_t n_therm = 0;
     if (a->thermal_mode) for (int64_t s = 0; s < n; ++s) if ((a->step0 + s) % 20 == 0) ++n_therm;
     if (a->thermal_mode == 2 && (n_therm > a->n_q || (need_ptrs && n_therm > 0 && !a->q_planes)))
@@ -1321,9 +1331,10 @@ static int upload_run_inputs(Handle* h, const cetkmc_run_args* a, int64_t n_ther
     if (a->thermal_mode == 2) CHK(grow(&h->d_q, &h->cap_q, (size_t)std::max<int64_t>(n_therm, 1) * L2));
     // the small arrays travel through the page-locked staging buffer (queued copies); a large one goes directly
     struct Part { void* dst; const void* src; size_t bytes; };
-    const Part parts[4] = {{h->d_u_pick, a->u_pick, n > 0 ? (size_t)n * 8 : 0},
-                           {h->d_u_defect, a->u_defect, (n > 0 && a->u_defect) ? (size_t)n * 8 : 0},
-                           {h->d_u_np, a->u_np, a->np_cap > 0 ? (size_t)a->np_cap * 8 : 0},
+    const bool streams = a->rng_mode != 2;
+    const Part parts[4] = {{h->d_u_pick, a->u_pick, (streams && n > 0 && a->u_pick) ? (size_t)n * 8 : 0},
+                           {h->d_u_defect, a->u_defect, (streams && n > 0 && a->u_defect) ? (size_t)n * 8 : 0},
+                           {h->d_u_np, a->u_np, (streams && a->np_cap > 0 && a->u_np) ? (size_t)a->np_cap * 8 : 0},
                            {h->d_q, a->q_planes, (a->thermal_mode == 2 && n_therm > 0) ? (size_t)n_therm * L2 * 8 : 0}};
     size_t small = 0;
     for (const Part& q : parts) if (q.bytes && q.bytes <= PIN_SMALL_MAX) small += q.bytes;
@@ -1369,7 +1380,7 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
     if (!h || !a || !res) return fail("null argument");
     const int64_t n = a->n_steps;
     // all input pointers NULL: the batch's inputs were put on the device by cetkmc_stage_inputs (same batch shape)
-    const bool staged = n > 0 && !a->u_pick && !a->u_defect && !a->u_np && !a->q_planes;
+    const bool staged = n > 0 && a->rng_mode != 2 && !a->u_pick && !a->u_defect && !a->u_np && !a->q_planes;
     int64_t n_therm = 0;
     CHK(check_run_args(h, a, !staged, &n_therm));
     const auto g = h->staged;
@@ -1390,6 +1401,7 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
     BatchCfg cfg{};
     cfg.step0 = a->step0; cfg.np_cap = a->np_cap; cfg.defect_fraction = a->defect_fraction; cfg.seed = a->seed;
     cfg.rng_mode = a->rng_mode; cfg.batch = 1;
+    if (a->rng_mode == 2) cfg.np_cap = INT64_MAX / 2;       // no stream to run out of
     // profile 1: two events per step around the rate-sweep kernel (bench roofline); profile 2: seven per step
     // (thermal | interface | sweep | reduce(+all-gather) | select+apply boundaries) for cetkmc_get_counters
     const int EPS = a->profile == 2 ? 7 : 2;
@@ -1411,9 +1423,14 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
     // re-evaluates the whole list before every full sweep
     const int eval_touched = (h->sweep_variant >= 1 && !h->ifc_every_step) ? 1 : 0;
     res->full_sweeps = 0;
+    // continuation of a batch that ran out of stream on a temperature-update step: that update is already in the field
+    const int64_t therm_skip_g = h->therm_applied_g;
+    h->therm_applied_g = -1;
     for (int64_t s = 0; s < n; ++s) {
         const int64_t g = a->step0 + s;
-        const bool therm = a->thermal_mode && g % 20 == 0;
+        const bool therm_due = a->thermal_mode && g % 20 == 0;
+        const bool therm = therm_due && !(s == 0 && g == therm_skip_g);
+        if (therm_due && !therm && a->thermal_mode == 2) ++q_idx;      // its source plane was consumed by the stopped batch
         if (incr && s > 0 && !therm) {
             // exact incremental step: rates can only have changed in the rows recorded by the last apply
             ++h->cnt.incremental_steps;
@@ -1512,6 +1529,17 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
     }
     h->cnt.steps += ss.cur;
     const int64_t done = ss.cur;
+    if (ss.status != 0) {
+        // the batch stopped early: the steps still queued behind the stop ran as pass-throughs (temperature copied through,
+        // buffer pair flipped, rate table / interface kernels returning at once), so the host's freshness flags describe
+        // work the device skipped.  Recompute both from the field as it stands.
+        h->table_fresh = false; h->ifc_fresh = false; h->swept = false;
+        if (ss.status == 2 && a->thermal_mode && done < n && (a->step0 + done) % 20 == 0 &&
+            !(done == 0 && a->step0 == therm_skip_g))
+            h->therm_applied_g = a->step0 + done;          // that step's update ran before the shortage was noticed
+        else if (ss.status == 2 && done == 0 && a->step0 == therm_skip_g)
+            h->therm_applied_g = therm_skip_g;             // still the same pending step (nothing executed, nothing updated)
+    }
     const int64_t nt = done + (ss.status == 1 ? 1 : 0);
     if (totals && ss.status == 1 && nt <= n) totals[done] = ss.total;
     h->cnt.bytes_d2h += (totals ? n * 8 : 0) + (events ? n * (int64_t)sizeof(cetkmc_event) : 0) + (n_events ? n * 8 : 0);
@@ -1530,15 +1558,44 @@ int cetkmc_get_counters(void* handle, cetkmc_counters* out, int reset)
 }
 
 // ---- Mode B: synchronous super-steps over spatial boxes (superstep.hpp) ------------------------------
+// kmc_simulation.py:331-332 per executed event of super-step g (DESIGN.md "Mode B": time advance; oracle orc_run_supersteps)
+static double superstep_dt_event(uint64_t seed, int64_t g, double total)
+{
+    const double u = counter_uniform(seed, (uint64_t)g, KEY_DT);
+    const double um = (u > 1e-12) ? u : 1e-12;              // max(1e-12, u)
+    const double dt = -std::log(um) / total;
+    return (1e-12 > dt) ? 1e-12 : dt;                       // max(dt, 1e-12)
+}
+
 int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_result* res, double* totals,
-                          cetkmc_event* events, int64_t* n_executed)
+                          cetkmc_event* events, int64_t* n_executed, double* dt_event)
 {
     Handle* h = (Handle*)handle;
     if (!h || !a || !res) return fail("null argument");
     const int64_t n = a->n_steps;
     if (n < 0) return fail("n_steps < 0");
     if (h->sweep_variant < 1) return fail("cetkmc_run_supersteps needs a streaming sweep_variant (1 or 2)");
-    if (a->box < 8 || a->box > 16 || (a->box & 1) || h->L % a->box) return fail("box must be even, 8..16, and divide L");
+    if (a->box == h->L) {
+        // single domain (window = whole lattice, no octants): one event per super-step from the global canonical tree --
+        // this IS a Mode A step whose uniforms are the counter-based ones of box 0, so it runs through the Mode A kernels
+        if (multi_rank(h) && h->nranks > 1) return fail("the single-domain case (box == L) runs in one process");
+        cetkmc_run_args ra{};
+        ra.step0 = a->step0; ra.n_steps = n; ra.defect_fraction = a->defect_fraction;
+        ra.rng_mode = 2; ra.seed = a->seed; ra.thermal_mode = a->thermal_mode; ra.thermal_dt = a->thermal_dt;
+        ra.q_planes = a->q_planes; ra.n_q = a->n_q; ra.use_latent = a->use_latent;
+        std::vector<double> tot((size_t)n + 1, 0.0);
+        CHK(cetkmc_run_steps(handle, &ra, res, tot.data(), events, nullptr));
+        const int64_t done = res->steps_done;
+        for (int64_t s = 0; s < done; ++s) {
+            if (totals) totals[s] = tot[(size_t)s];
+            if (n_executed) n_executed[s] = 1;
+            if (dt_event) dt_event[s] = superstep_dt_event(a->seed, a->step0 + s, tot[(size_t)s]);
+        }
+        if (totals && res->status == 1 && done < n) totals[done] = tot[(size_t)done];
+        h->cnt.supersteps += done;
+        return 0;
+    }
+    if (a->box < 8 || a->box > 16 || (a->box & 1) || h->L % a->box) return fail("box must be even, 8..16, and divide L (or equal L: single domain)");
     const bool ranks = multi_rank(h) && h->nranks > 1;
     if (ranks && (h->L / h->nranks) % a->box) return fail("across ranks the boxes must be aligned to the slabs: (L / nranks) % box == 0");
     int64_t n_therm = 0;
@@ -1558,6 +1615,8 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
     C.d0 = ranks ? (h->own_i0 / a->box) * nb2 : 0;
     const int D = ranks ? ((h->own_i1 - h->own_i0) / a->box) * nb2 : C.nb * nb2;
     C.D_loc = D;
+    C.null_events = a->null_events ? 1 : 0;
+    C.nranks = ranks ? h->nranks : 1;
     const int NE = D + 2 * nb2;                               // own events | lower neighbour's top layer | upper neighbour's bottom layer
     const size_t shmem = (size_t)C.PT * C.PH * C.PH * 19;     // heap: 2*NL doubles + 2*NL flags, NL leaf codes
     h->staged.valid = false;            // the batch buffers are reused below
@@ -1574,8 +1633,12 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
     // per-call device buffers, released on every return path
     struct Tmp {
         cetkmc_event* dom = nullptr; DomPick* picks = nullptr; unsigned long long* cnt = nullptr; cetkmc_event* log = nullptr;
-        ~Tmp() { (void)hipFree(dom); (void)hipFree(picks); (void)hipFree(cnt); (void)hipFree(log); }
+        double* rmax = nullptr;
+        ~Tmp() { (void)hipFree(dom); (void)hipFree(picks); (void)hipFree(cnt); (void)hipFree(log); (void)hipFree(rmax); }
     } tmp;
+    double*& d_rmax = tmp.rmax;
+    HIPCHK(hipMalloc((void**)&d_rmax, (size_t)std::max(C.nranks, 1) * sizeof(double)));
+    HIPCHK(hipMemsetAsync(d_rmax, 0, (size_t)std::max(C.nranks, 1) * sizeof(double), h->stream));
     cetkmc_event*& d_dom = tmp.dom;
     DomPick*& d_picks = tmp.picks;
     unsigned long long*& d_cnt = tmp.cnt;
@@ -1622,8 +1685,14 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
         else
             hipLaunchKernelGGL(k_domain_pick, dim3(D), dim3(64), shmem, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
                                (int)h->slabs.size(), h->L, C, (const StepState*)h->d_ss, (const double*)h->d_ktab, d_picks);
+        if (C.null_events) {
+            // R_max of the super-step: this rank's largest window total, then (across ranks) the largest of all ranks
+            hipLaunchKernelGGL(k_domain_rmax, dim3(1), dim3(1024), 0, h->stream, (const DomPick*)d_picks, D, (const StepState*)h->d_ss,
+                               d_rmax, ranks ? h->rank : 0);
+            if (ranks) CHK(comm_allgather(h, d_rmax, sizeof(double)));
+        }
         hipLaunchKernelGGL(k_domain_apply, dim3((D + 63) / 64), dim3(64), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
-                           (int)h->slabs.size(), h->L, D, C, h->d_ss, (const DomPick*)d_picks, d_dom, d_cnt, d_log);
+                           (int)h->slabs.size(), h->L, D, C, h->d_ss, (const DomPick*)d_picks, d_dom, d_cnt, d_log, (const double*)d_rmax);
         int n_touch = D;
         if (ranks) {
             // the events of my bottom / top box layer go to the ranks below / above, theirs come here: every rank applies
@@ -1650,10 +1719,16 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     res->wall_ms = ms; res->sweep_ms_total = 0.0; res->sweep_launches = 0; res->full_sweeps = n;
     h->cnt.supersteps += ss.cur;
+    if (ss.status != 0) { h->table_fresh = false; h->ifc_fresh = false; h->swept = false; }     // as in cetkmc_run_steps
     CHK(refresh_ifc_grid(h));
     const int64_t done = ss.cur;
     if (totals && done > 0) HIPCHK(hipMemcpy(totals, h->d_log_total, (size_t)done * 8, hipMemcpyDeviceToHost));
     if (totals && ss.status == 1 && done < n) totals[done] = ss.total;
+    if (dt_event && done > 0) {
+        std::vector<double> tot((size_t)done);
+        HIPCHK(hipMemcpy(tot.data(), h->d_log_total, (size_t)done * 8, hipMemcpyDeviceToHost));
+        for (int64_t s = 0; s < done; ++s) dt_event[s] = superstep_dt_event(a->seed, a->step0 + s, tot[(size_t)s]);
+    }
     if (n_executed && done > 0) HIPCHK(hipMemcpy(n_executed, h->d_log_nev, (size_t)done * 8, hipMemcpyDeviceToHost));
     if (events && done > 0) HIPCHK(hipMemcpy(events, d_log, (size_t)done * D * sizeof(cetkmc_event), hipMemcpyDeviceToHost));
     return 0;

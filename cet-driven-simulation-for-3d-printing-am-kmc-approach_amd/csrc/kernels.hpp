@@ -41,7 +41,7 @@ struct BatchCfg {
     int64_t np_cap;
     double defect_fraction;
     uint64_t seed;
-    int32_t rng_mode;
+    int32_t rng_mode;   // 0 reference stream, 1 counter species draw, 2 every uniform counter based (no host streams)
     int32_t batch;      // 1: r = u_pick[cur]*total and RNG bookkeeping; 0: direct r
 };
 
@@ -682,6 +682,31 @@ __global__ __launch_bounds__(64) void k_plane_reduce(SlabView S, BlockEnt* __res
     plane_reduce_wave<false>(S.rowsum, S.rowcnt, blocks, S.L, S.Pk, S.gi0, b / 3, b % 3, (int)threadIdx.x);
 }
 
+// ---- counter-based uniforms (DESIGN.md "RNG"): u(seed, step, key) in [0, 1); the oracle's orc_counter_uniform ----------
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t x)
+{
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL;
+    x ^= x >> 27; x *= 0x94D049BB133111EBULL;
+    x ^= x >> 31;
+    return x;
+}
+__host__ __device__ __forceinline__ double counter_uniform(uint64_t seed, uint64_t step, uint64_t site)
+{
+    uint64_t x = mix64(seed + 0x9E3779B97F4A7C15ULL * (step + 1));
+    x = mix64(x ^ (site * 0xD6E8FEB86659FD93ULL + 0x2545F4914F6CDD1DULL));
+    return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+}
+// keys of the per-box uniforms of Mode B (| box index) -- and, with box index 0, of the all-counter Mode A stream (rng_mode 2);
+// the deposition species is keyed by j * L + k in both (as rng_mode 1)
+constexpr uint64_t KEY_PICK = 1ull << 40, KEY_THETA = 2ull << 40, KEY_PHI = 3ull << 40, KEY_DEFECT = 4ull << 40,
+                   KEY_ACCEPT = 5ull << 40, KEY_DT = 6ull << 40;
+__device__ __forceinline__ int dep_species(const KParams& P, double u)
+{   // kmc_event_rates.py:66-71
+    if (u < P.impurity_c) return 3;
+    if (u < P.impurity_c + P.impurity_re) return 2;
+    return 1;
+}
+
 // A/B instrumentation (tools/sel_stamps.py, alternative build with -DCETKMC_SEL_STAMPS): thread 0 records the 100 MHz
 // wall clock at the phase boundaries of the fused selection + application kernel
 #ifdef CETKMC_SEL_STAMPS
@@ -830,9 +855,18 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
         np_pos0 = ss->np_pos;
         nuc0 = ss->nuc_count;
         cur = cur_hint >= 0 ? cur_hint : ss->cur;
-        u0 = u_pick[cur];
-        if (carry && u_defect && cfg.defect_fraction > 0.0) u_def = u_defect[cur];
-        if (carry && u_np && cfg.rng_mode == 1 && np_pos0 + 2 <= cfg.np_cap) { u_th = u_np[np_pos0]; u_ph = u_np[np_pos0 + 1]; }
+        if (cfg.rng_mode == 2) {            // the single-domain super-step's uniforms (oracle orc_run_supersteps, box == L)
+            const uint64_t g = (uint64_t)(cfg.step0 + cur);
+            u0 = counter_uniform(cfg.seed, g, KEY_PICK);
+            if (carry) {
+                if (cfg.defect_fraction > 0.0) u_def = counter_uniform(cfg.seed, g, KEY_DEFECT);
+                u_th = counter_uniform(cfg.seed, g, KEY_THETA); u_ph = counter_uniform(cfg.seed, g, KEY_PHI);
+            }
+        } else {
+            u0 = u_pick[cur];
+            if (carry && u_defect && cfg.defect_fraction > 0.0) u_def = u_defect[cur];
+            if (carry && u_np && cfg.rng_mode == 1 && np_pos0 + 2 <= cfg.np_cap) { u_th = u_np[np_pos0]; u_ph = u_np[np_pos0 + 1]; }
+        }
     }
     if (tid == 0 && carry) carry->ready = 0;
     const SlabView S0 = slabs[0];
@@ -1426,27 +1460,6 @@ __device__ __forceinline__ void apply_touch(const KParams& P, const SlabView* sl
     }
 }
 
-__device__ __forceinline__ uint64_t mix64(uint64_t x)
-{
-    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL;
-    x ^= x >> 27; x *= 0x94D049BB133111EBULL;
-    x ^= x >> 31;
-    return x;
-}
-// counter-based uniform for the deposition species in rng_mode 1 (DESIGN.md "RNG")
-__device__ __forceinline__ double counter_uniform(uint64_t seed, uint64_t step, uint64_t site)
-{
-    uint64_t x = mix64(seed + 0x9E3779B97F4A7C15ULL * (step + 1));
-    x = mix64(x ^ (site * 0xD6E8FEB86659FD93ULL + 0x2545F4914F6CDD1DULL));
-    return (double)(x >> 11) * (1.0 / 9007199254740992.0);
-}
-__device__ __forceinline__ int dep_species(const KParams& P, double u)
-{   // kmc_event_rates.py:66-71
-    if (u < P.impurity_c) return 3;
-    if (u < P.impurity_c + P.impurity_re) return 2;
-    return 1;
-}
-
 // Batched apply: RNG bookkeeping of one step + lattice update + per-step logs (lane 0), then the
 // interface-list update for the touched voxels (whole wave).  Launched with ONE 64-thread block.
 __device__ __forceinline__ void apply_batch_body(const KParams& P, const SlabView* __restrict__ slabs, int nslabs, int L,
@@ -1481,13 +1494,17 @@ __device__ __forceinline__ void apply_batch_body(const KParams& P, const SlabVie
                 }
                 if (cfg.rng_mode == 0) pos += n_dep;
                 if (ev.type == EV_DEP || ev.type == EV_NUC) {
-                    const double ut = have ? carry->u_th : u_np[pos], up = have ? carry->u_ph : u_np[pos + 1];
+                    const uint64_t gs = (uint64_t)(cfg.step0 + s);
+                    const double ut = have ? carry->u_th : (cfg.rng_mode == 2 ? counter_uniform(cfg.seed, gs, KEY_THETA) : u_np[pos]);
+                    const double up = have ? carry->u_ph : (cfg.rng_mode == 2 ? counter_uniform(cfg.seed, gs, KEY_PHI) : u_np[pos + 1]);
                     ev.theta = 0.0 + (3.141592653589793 - 0.0) * ut;       // np.random.uniform(0, pi)
                     ev.phi = 0.0 + (6.283185307179586 - 0.0) * up;         // np.random.uniform(0, 2*pi)
-                    pos += 2;
+                    if (cfg.rng_mode != 2) pos += 2;
                     if (ev.type == EV_NUC) { if (have) ss->nuc_count = carry->nuc_count + 1; else ss->nuc_count += 1; }
                 }
-                const int mk = (cfg.defect_fraction > 0.0 && (have ? carry->u_def : u_defect[s]) < cfg.defect_fraction) ? 1 : 0;
+                const int mk = (cfg.defect_fraction > 0.0 &&
+                                (have ? carry->u_def
+                                      : (cfg.rng_mode == 2 ? counter_uniform(cfg.seed, (uint64_t)(cfg.step0 + s), KEY_DEFECT) : u_defect[s])) < cfg.defect_fraction) ? 1 : 0;
                 apply_event(slabs, nslabs, ev, mk, (have && (ev.type == EV_DEP || ev.type == EV_NUC)) ? carry->ov : nullptr);
                 ss->np_pos = pos;
                 if (log_total) log_total[s] = have ? carry->total : ss->total;

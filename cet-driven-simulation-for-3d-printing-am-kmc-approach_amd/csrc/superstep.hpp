@@ -10,8 +10,6 @@
 
 namespace cetkmc {
 
-constexpr uint64_t KEY_PICK = 1ull << 40, KEY_THETA = 2ull << 40, KEY_PHI = 3ull << 40, KEY_DEFECT = 4ull << 40;
-
 constexpr int SUPER_CNT_SLOTS = 256, SUPER_CNT_STRIDE = 16;     // per-slot {executed, nucleations} counters, 128 B apart
 
 struct SuperCfg {
@@ -21,6 +19,8 @@ struct SuperCfg {
     int32_t box, H, PH, PT;     // box edge, window edge (box/2), pow2(H), pow2(3H)
     int32_t nb;                 // boxes per axis
     int32_t d0, D_loc;          // this handle's boxes: global indices [d0, d0 + D_loc) (box layers of its owned planes)
+    int32_t null_events;        // 1: a box executes its pick with probability R_d / R_max, else a null event (type -2)
+    int32_t nranks;             // entries of the gathered per-rank maxima (1 in a single process)
 };
 
 // The slot scan of kmc_simulation.py:268-274 inside ONE chosen voxel by a whole wave: lane m < 14 evaluates the rate of
@@ -91,6 +91,7 @@ struct DomPick {          // the chosen event of one box, before the uniforms ar
     int32_t type;          // EV_*; < 0: idle box
     int32_t m, atom;       // neighbour slot (or -1), species
     double rate;
+    double R;              // total rate of the box's window (canonical window tree); 0 for an idle box
 };
 
 // One wave per box: leaves = category sums of the window's voxels, LDS heap of NL = PT*PH*PH leaves built by the wave
@@ -199,6 +200,7 @@ __global__ __launch_bounds__(64) void k_domain_pick(KParams P, const SlabView* _
     }
     DomPick pk;
     pk.i = pi; pk.j = pj; pk.k = pkk; pk.type = -1; pk.m = -1; pk.atom = 0; pk.rate = 0.0;
+    pk.R = (cat >= 0) ? R : 0.0;
     if (cat >= 0) {                                              // wave-uniform
         if (simple) {            // the deposition of this voxel / the nucleation of a bulk empty voxel: nothing to scan
             pk.type = (cat == CAT_DEP) ? EV_DEP : EV_NUC;
@@ -304,8 +306,9 @@ __global__ __launch_bounds__(64) void k_domain_pick8(KParams P, const SlabView* 
     const unsigned long long mask = __ballot(fm != 0u);
     const double R = lv[6];
     DomPick pk;
-    pk.i = 0; pk.j = 0; pk.k = 0; pk.type = -1; pk.m = -1; pk.atom = 0; pk.rate = 0.0;
+    pk.i = 0; pk.j = 0; pk.k = 0; pk.type = -1; pk.m = -1; pk.atom = 0; pk.rate = 0.0; pk.R = 0.0;
     if (mask != 0ull && !(R < 1e-25) && finite_d(R)) {       // wave-uniform
+        pk.R = R;
         const double r = counter_uniform(C.seed, (uint64_t)g, KEY_PICK | (uint64_t)d) * R;
         double base = 0.0;
         int a = 0;
@@ -348,13 +351,34 @@ __global__ __launch_bounds__(64) void k_domain_pick8(KParams P, const SlabView* 
     if (lane == 0 && !status) picks[dl] = pk;
 }
 
+// Null events: R_max of this rank's boxes (one block; picks are L2-resident, written by the pick kernel just before) into
+// rmax[rank]; across ranks the entries are all-gathered and k_domain_apply takes the largest.
+__global__ __launch_bounds__(1024) void k_domain_rmax(const DomPick* __restrict__ picks, int D, const StepState* __restrict__ ss,
+                                                       double* __restrict__ rmax, int rank)
+{
+    __shared__ double wm[16];
+    if (ss->status) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    double m = 0.0;
+    for (int d = tid; d < D; d += 1024) { const DomPick& p = picks[d]; if (p.type >= 0 && p.R > m) m = p.R; }
+#pragma unroll
+    for (int l = 0; l < 6; ++l) { const double o = __shfl_xor(m, 1 << l); m = o > m ? o : m; }
+    if (lane == 0) wm[w] = m;
+    __syncthreads();
+    if (tid == 0) {
+        for (int q = 1; q < 16; ++q) m = wm[q] > m ? wm[q] : m;
+        rmax[rank] = m;
+    }
+}
+
 // One thread per box: event record, uniforms, lattice write (kmc_simulation.py:276-327).  Reads stay within +-2 of the
 // chosen voxel and so do the writes of every other box's event (>= 5 away on some axis): no box reads what another writes.
 __global__ __launch_bounds__(64) void k_domain_apply(KParams P, const SlabView* __restrict__ slabs, int nslabs, int L, int D,
                                                      SuperCfg C, StepState* ss, const DomPick* __restrict__ picks,
                                                      cetkmc_event* __restrict__ dom_events,
                                                      unsigned long long* counters /* per slot: [0] executed, [1] nucleations */,
-                                                     cetkmc_event* log_events /* [n][D] or null */)
+                                                     cetkmc_event* log_events /* [n][D] or null */,
+                                                     const double* __restrict__ rmax /* [C.nranks] window-total maxima (null events) */)
 {
     if (ss->status) return;
     const int dl = blockIdx.x * 64 + threadIdx.x;       // local box
@@ -368,17 +392,29 @@ __global__ __launch_bounds__(64) void k_domain_apply(KParams P, const SlabView* 
     ev.pos[0] = ev.pos[1] = ev.pos[2] = 0;
     ev.target[0] = ev.target[1] = ev.target[2] = -1;
     ev.atom = 0; ev.rate = 0.0; ev.dep_rank = -1; ev.theta = 0.0; ev.phi = 0.0;
+    bool accepted = true;
+    if (pk.type >= 0 && C.null_events) {
+        double Rmax = rmax[0];
+        for (int q = 1; q < C.nranks; ++q) Rmax = rmax[q] > Rmax ? rmax[q] : Rmax;
+        accepted = counter_uniform(C.seed, (uint64_t)g, KEY_ACCEPT | (uint64_t)d) * Rmax < pk.R;
+    }
     if (pk.type >= 0) {
         const int i = pk.i, j = pk.j, k = pk.k;
         ev.pos[0] = i; ev.pos[1] = j; ev.pos[2] = k;
         ev.atom = pk.atom; ev.rate = pk.rate;
+        if (pk.m >= 0) {
+            ev.target[0] = i + nbi_rt(pk.m); ev.target[1] = j + nbj_rt(pk.m); ev.target[2] = k + nbk_rt(pk.m);
+        }
+    }
+    if (!accepted) ev.type = -2;        // null event: the pick is logged, nothing is drawn or applied
+    if (ev.type >= 0) {
+        const int i = pk.i, j = pk.j, k = pk.k;
         if (pk.m >= 0) {
             int sl = 0;
             for (int s = 0; s < nslabs; ++s) if (i >= slabs[s].gi0 && i < slabs[s].gi0 + slabs[s].nloc) sl = s;
             const SlabView& S = slabs[sl];
             const int li = i - S.gi0 + 2;
             const int ai = nbi_rt(pk.m), aj = nbj_rt(pk.m), ak = nbk_rt(pk.m);
-            ev.target[0] = i + ai; ev.target[1] = j + aj; ev.target[2] = k + ak;
             const int64_t src = (pk.type == EV_DIFF) ? S.tidx(li, j, k) : S.tidx(li + ai, j + aj, k + ak);
             ev.theta = S.theta[src]; ev.phi = S.phi[src];
         }

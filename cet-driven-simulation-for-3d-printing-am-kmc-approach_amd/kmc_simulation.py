@@ -12,6 +12,10 @@ sweep, cumulative-rate event pick, lattice update -- runs on the device in batch
   * runs the analysis that is not part of the hot path (defect-mask refresh and metrics every
     ``METRIC_UPDATE_STEP`` steps).
 
+``run_kmc(mode="B", box=8)`` runs the same model through the synchronous super-step engine (``cetkmc_run_supersteps``:
+thousands of events per rate sweep, NOT the reference's trajectory -- DESIGN.md "Mode B"), with the same prints and the same
+18-column ``metrics.csv``.
+
 There is no CPU fallback; without libcetkmc_hip.so + a GPU this raises.
 """
 import os
@@ -131,6 +135,12 @@ def run_kmc(
     resume_from: str = None,
     incremental: bool = True,
     nu_dep: float = None,
+    mode: str = "A",
+    box: int = 8,
+    null_events: bool = True,
+    thermal_cadence: str = "events",
+    seed: int = None,
+    metrics_every: int = METRIC_UPDATE_STEP,
 ):
     """KMC microstructure evolution with natural defect injection (same contract as the
     reference).  ``defect_fraction`` is the per-event probability that the just-updated voxel
@@ -142,8 +152,30 @@ def run_kmc(
     ``incremental=False`` re-evaluates the whole lattice on every step like get_event_rates does (the
     default re-evaluates only the rows an event made stale between temperature updates -- same results);
     ``nu_dep`` overrides constants.NU_DEP (deposition attempt frequency = growth velocity V of the G-V sweep
-    driver gv_sweep.py; the reference can only change it by editing constants.py)."""
+    driver gv_sweep.py; the reference can only change it by editing constants.py);
+    ``seed`` replaces constants.RANDOM_SEED for both host generators (and keys Mode B's counter uniforms);
+    ``metrics_every`` replaces constants.METRIC_UPDATE_STEP (cadence of the metrics rows and of the defect-mask refresh).
+
+    ``mode="B"``: synchronous super-steps over ``(L/box)**3`` boxes (cetkmc_run_supersteps; ``box == L`` is the
+    single-domain case = the exact loop with counter uniforms).  ``n_steps`` keeps its meaning -- the number of EXECUTED
+    events -- and the run ends with the first super-step that reaches it (it may overshoot by less than one super-step;
+    the last row's ``Step`` says by how much).  ``Step`` of a row = index of the last executed event, rows are written by
+    the first super-step that reaches each multiple of ``metrics_every`` (and by the last one), ``Time`` advances per
+    executed event as kmc_simulation.py:331-332 does.  ``null_events`` (default on): boxes execute with probability
+    R_box / R_max, which makes every event's frequency proportional to its rate as in the reference's global pick.
+    ``thermal_cadence="events"`` (default) keeps the reference's cadence of one temperature update per 20 executed events
+    (kmc_simulation.py:248-250): before every super-step the field is brought to ``executed // 20 + 1`` updates;
+    ``"supersteps"`` updates once per 20 super-steps inside the engine (throughput setting for large lattices: the
+    temperature history per executed event then differs from the reference's)."""
     import cetkmc
+    if mode not in ("A", "B"):
+        raise ValueError("mode must be 'A' (exact, one event per sweep) or 'B' (super-steps)")
+    if thermal_cadence not in ("events", "supersteps"):
+        raise ValueError("thermal_cadence must be 'events' or 'supersteps'")
+    if mode == "B" and (checkpoint_every or resume_from):
+        raise ValueError("checkpoint / resume is implemented for mode 'A' only")
+    run_seed = RANDOM_SEED if seed is None else int(seed)
+    metrics_every = int(metrics_every)
 
     output_dir = f"outputs/{output_prefix}"
     os.makedirs(output_dir, exist_ok=True)
@@ -154,8 +186,8 @@ def run_kmc(
         atom_type = state.copy()
         defects_mask = ckpt["defects"]
     else:
-        np.random.seed(RANDOM_SEED)
-        random.seed(RANDOM_SEED)
+        np.random.seed(run_seed)
+        random.seed(run_seed)
         state, theta, phi, T, atom_type = initialize_lattice(
             lattice_size=L, n_seeds=n_seeds, T_sub=temp, impurity_c=impurity_c)
         defects_mask, defect_density = introduce_defects(state, atom_type, T, apply_to_state=False)
@@ -171,6 +203,9 @@ def run_kmc(
     engine = cetkmc.Engine(L, impurity_c=impurity_c, params=params)
     engine.upload(state, theta, phi, T, defects_mask)
     n_flagged = int(np.sum(defects_mask))
+    if mode == "B" and not (box == L or (box in (8, 10, 12, 14, 16) and L % box == 0)):
+        engine.close()
+        raise ValueError("mode 'B': box must be even, 8..16, and divide L (or equal L: single domain)")
 
     total_time = 0.0
     metrics_data = []
@@ -182,35 +217,12 @@ def run_kmc(
         total_time, metrics_data, cet_detected = ckpt["total_time"], ckpt["metrics_data"], ckpt["cet_detected"]
         next_step, nuc_offset = ckpt["next_step"], ckpt["nucleation_count"]
         step = next_step - 1
-    while next_step < n_steps:
-        # next step after which the host has work: metrics (and, on multiples of
-        # METRIC_UPDATE_STEP, the defect-mask refresh) -- kmc_simulation.py:335-341
-        stop = next_step if next_step % METRIC_UPDATE_STEP == 0 else \
-            min((next_step // METRIC_UPDATE_STEP + 1) * METRIC_UPDATE_STEP, n_steps - 1)
-        stop = min(stop, n_steps - 1)
-        if checkpoint_every > 0:      # also stop right before every checkpoint boundary
-            stop = min(stop, (next_step // checkpoint_every + 1) * checkpoint_every - 1)
-        done, terminated, last_total, dts = _advance_to(engine, next_step, stop, L, defect_fraction, incremental=incremental)
-        for dt in dts:
-            total_time += dt
-        if terminated:
-            step = next_step + done
-            print(f"Terminating at step {step}: no valid events (rate={last_total:.2e})")
-            break
-        step = stop
-        next_step = stop + 1
-
-        is_metric_step = (step % METRIC_UPDATE_STEP == 0) or (step == n_steps - 1)
-        if not is_metric_step:        # a pure checkpoint stop
-            fields = engine.download()
-            save_checkpoint(os.path.join(output_dir, "checkpoint.npz"), fields, engine.download(state=False, theta=False,
-                            phi=False, T=False, defects=True)["defects"], next_step, total_time,
-                            nuc_offset + engine.nucleation_count(), metrics_data, cet_detected)
-            continue
-        # Host work of a metrics step WITHOUT moving the lattice: the defect mask is refreshed from the
-        # carbon sites only, grains are clustered on the GPU, species are counted on the GPU.
-        if step % METRIC_UPDATE_STEP == 0:
-            n_flagged, defect_density = refresh_defects_device(engine)       # kmc_simulation.py:335-338
+    def metrics_row(step, refresh_defects):
+        """kmc_simulation.py:335-389 for the lattice as it stands after event index `step` -- WITHOUT moving the lattice: the
+        defect mask is refreshed from the carbon sites only, grains are clustered and species counted on the GPU."""
+        nonlocal n_flagged, cet_detected
+        if refresh_defects:
+            n_flagged, _ = refresh_defects_device(engine)       # kmc_simulation.py:335-338
         m = compute_metrics_device(engine, L ** 3, defects_count=n_flagged, voxel_size=VOXEL_SIZE)
         counts = engine.species_counts()
         defect_voxels = int(counts[DEFECT_ID])
@@ -250,10 +262,73 @@ def run_kmc(
             f"Detected={row['CET_Detected']}, "
             f"Time={row['Time']:.2e}s"
         )
+
+    while mode == "A" and next_step < n_steps:
+        # next step after which the host has work: metrics (and, on multiples of
+        # metrics_every, the defect-mask refresh) -- kmc_simulation.py:335-341
+        stop = next_step if next_step % metrics_every == 0 else \
+            min((next_step // metrics_every + 1) * metrics_every, n_steps - 1)
+        stop = min(stop, n_steps - 1)
+        if checkpoint_every > 0:      # also stop right before every checkpoint boundary
+            stop = min(stop, (next_step // checkpoint_every + 1) * checkpoint_every - 1)
+        done, terminated, last_total, dts = _advance_to(engine, next_step, stop, L, defect_fraction, incremental=incremental)
+        for dt in dts:
+            total_time += dt
+        if terminated:
+            step = next_step + done
+            print(f"Terminating at step {step}: no valid events (rate={last_total:.2e})")
+            break
+        step = stop
+        next_step = stop + 1
+
+        is_metric_step = (step % metrics_every == 0) or (step == n_steps - 1)
+        if not is_metric_step:        # a pure checkpoint stop
+            fields = engine.download()
+            save_checkpoint(os.path.join(output_dir, "checkpoint.npz"), fields, engine.download(state=False, theta=False,
+                            phi=False, T=False, defects=True)["defects"], next_step, total_time,
+                            nuc_offset + engine.nucleation_count(), metrics_data, cet_detected)
+            continue
+        metrics_row(step, step % metrics_every == 0)
         if checkpoint_every > 0 and next_step % checkpoint_every == 0:
             save_checkpoint(os.path.join(output_dir, "checkpoint.npz"), engine.download(),
                             engine.download(state=False, theta=False, phi=False, T=False, defects=True)["defects"],
                             next_step, total_time, nuc_offset + engine.nucleation_count(), metrics_data, cet_detected)
+
+    if mode == "B":
+        # Super-step loop.  executed = events executed so far = index of the next event; g = super-step index (octant
+        # g % 8, keys the counter uniforms together with run_seed).
+        nbx = L // box if (box and L % box == 0) else 1
+        d_max = 1 if box == L else nbx ** 3                       # events per super-step at most
+        executed, g, thermal_done = 0, 0, 0
+        by_events = thermal_cadence == "events"
+        while executed < n_steps:
+            # super-steps until (at the earliest) the next metrics boundary / the end: a super-step executes <= d_max events
+            # (a row is due once executed - 1 reaches the next multiple of metrics_every)
+            boundary = min(((executed - 1) // metrics_every + 1) * metrics_every + 1, n_steps)
+            nb = max(1, (boundary - executed) // d_max)
+            if by_events:
+                # kmc_simulation.py:248-250: event index e is preceded by e // 20 + 1 temperature updates; the super-step's
+                # events all see the field of its first event (the lattice and T are frozen within a super-step)
+                nb = 1
+                due = executed // THERMAL_EVERY + 1
+                for _ in range(due - thermal_done):
+                    engine.thermal_cet(THERMAL_DT, scrub_nan=True)
+                thermal_done = due
+            r = engine.run_supersteps(g, nb, box, defect_fraction, run_seed, thermal_mode=0 if by_events else 1,
+                                      thermal_dt=THERMAL_DT, null_events=null_events)
+            before = executed
+            for s in range(r["done"]):
+                executed += int(r["n_exec"][s])
+                total_time += int(r["n_exec"][s]) * float(r["dt_event"][s])
+            g += r["done"]
+            step = executed - 1
+            if r["status"] == 1:
+                print(f"Terminating at step {executed}: no valid events (rate={float(r['totals'][r['done']]):.2e})")
+                break
+            crossed = (executed - 1) // metrics_every > (before - 1) // metrics_every
+            if crossed or executed >= n_steps:
+                metrics_row(step, crossed)
+        next_step = executed
 
     if metrics_data:
         df = pd.DataFrame(metrics_data)

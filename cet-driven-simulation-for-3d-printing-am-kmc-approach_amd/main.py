@@ -5,7 +5,7 @@ back ``metrics.csv`` and classify the final microstructure.  Plotting is optiona
 only imported when ``--plots`` is given); the reference's visualization / graphs modules are
 outside the accelerated path and are not part of this package.
 
-    python main.py [--L 30] [--steps 20000] [--levels 0.0 0.1 0.2] [--plots]
+    python main.py [--L 30] [--steps 20000] [--levels 0.0 0.1 0.2] [--plots] [--mode B --box 8]
 """
 import argparse
 import os
@@ -20,7 +20,7 @@ from lattice_init import initialize_lattice, save_lattice
 from metrics import detect_CET_transition
 
 
-def main(L=LATTICE_SIZE, n_steps=N_STEPS, carbon_levels=(0.0, 0.1, 0.2), plots=False):
+def main(L=LATTICE_SIZE, n_steps=N_STEPS, carbon_levels=(0.0, 0.1, 0.2), plots=False, **run_kw):
     print("Starting KMC simulation for microstructure control...")
     t_start = time.time()
     summary = {"carbon_levels": [], "grain_sizes": [], "defect_densities": [], "aspect_ratios": []}
@@ -34,7 +34,7 @@ def main(L=LATTICE_SIZE, n_steps=N_STEPS, carbon_levels=(0.0, 0.1, 0.2), plots=F
         save_lattice(*init[:4], init[4], prefix=f"{out_dir}/init")
         t0 = time.time()
         state, atom_type, total_time, theta, phi = run_kmc(L=L, n_steps=n_steps, temp=T_SUB, defect_fraction=DEFECT_PROB,
-                                                           n_seeds=N_SEEDS, impurity_c=c, output_prefix=prefix)
+                                                           n_seeds=N_SEEDS, impurity_c=c, output_prefix=prefix, **run_kw)
         t1 = time.time()
         csv_path = f"outputs/{prefix}/metrics.csv"
         status = "Undetected"
@@ -64,5 +64,7 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=N_STEPS)
     ap.add_argument("--levels", type=float, nargs="*", default=[0.0, 0.1, 0.2])
     ap.add_argument("--plots", action="store_true")
+    ap.add_argument("--mode", choices=("A", "B"), default="A", help="A: exact loop (one event per sweep); B: super-steps")
+    ap.add_argument("--box", type=int, default=8)
     a = ap.parse_args()
-    main(a.L, a.steps, tuple(a.levels), a.plots)
+    main(a.L, a.steps, tuple(a.levels), a.plots, **(dict(mode="B", box=a.box) if a.mode == "B" else {}))

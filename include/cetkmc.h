@@ -92,7 +92,10 @@ typedef struct cetkmc_run_args {
     int64_t np_cap;           /* number of doubles in u_np                              */
     int32_t rng_mode;         /* 0: reference stream (n_dep species draws per step + 2 orientation
                                     draws per dep/nuc event);
-                                 1: counter-based species draw, stream holds only the orientation draws */
+                                 1: counter-based species draw, stream holds only the orientation draws;
+                                 2: every uniform counter based -- u(seed, step, key), the keys of Mode B's box 0 (pick
+                                    1<<40, theta 2<<40, phi 3<<40, defect 4<<40, species j*L+k): u_pick / u_defect / u_np
+                                    are not read and may be NULL.  This is what cetkmc_run_supersteps(box == L) runs */
     uint64_t seed;            /* rng_mode 1 key                                         */
     int32_t thermal_mode;     /* 0 none, 1 update_temperature_cet every 20 steps (:248-250),
                                  2 update_temperature (laser) every 20 steps             */
@@ -123,7 +126,13 @@ typedef struct cetkmc_run_result {
 /* Mode B -- synchronous super-steps (NOT in the reference; SURVEY.md section 8(f)4, DESIGN.md "Mode B").
  * The lattice is tiled by (L/box)^3 cubic boxes; every super-step runs the ordinary full rate sweep and then
  * every box executes at most one event picked from its active octant (octant = step % 8), so several thousand
- * events are executed per sweep.  box: even, 8..16, divides L.  All uniforms are counter based (seed, step, key).
+ * events are executed per sweep.  box: even, 8..16, divides L -- or box == L: ONE domain without octants, which is
+ * exactly a Mode A step (kmc_simulation.py:253-327) driven by the counter uniforms of box 0 (single process).
+ * All uniforms are counter based (seed, step, key).
+ * null_events: with R_max = the largest window total of the super-step, box d executes its pick only with probability
+ * R_d / R_max (else a null event, logged as type -2): every event of an active window then fires with probability
+ * rate / R_max per visit -- proportional to its rate everywhere, like the reference's global pick
+ * (kmc_simulation.py:265-274).  0: every non-idle box executes its pick (boxes with few events are over-sampled).
  * The trajectory is not the reference's; its bit-exact comparator is the oracle's orc_run_supersteps. */
 typedef struct cetkmc_super_args {
     int64_t step0;            /* global index of the first super-step (thermal cadence step%20, octant step%8) */
@@ -136,6 +145,7 @@ typedef struct cetkmc_super_args {
     const double* q_planes;
     int64_t n_q;
     int32_t use_latent;
+    int32_t null_events;      /* see above */
 } cetkmc_super_args;
 
 /* Work issued, bytes moved and (while cetkmc_run_args.profile == 2) device time per phase, accumulated on the
@@ -256,8 +266,11 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* args, cetkmc_run_resul
  * (bench.py: inputs resident in HBM before the timed region).  Any other stepping call drops the staged batch. */
 int cetkmc_stage_inputs(void* handle, const cetkmc_run_args* args);
 
-/* totals[n] (Mode A total of every super-step's sweep), events[n][D] or NULL (type -1: idle box),
- * n_executed[n] events applied per super-step.  res->np_used is 0.
+/* totals[n] (Mode A total of every super-step's sweep), events[n][D] or NULL (type -1: idle box, -2: null event),
+ * n_executed[n] events applied per super-step, dt_event[n] (or NULL) the time increment PER EXECUTED EVENT of every
+ * super-step: kmc_simulation.py:331-332 restated with the super-step's total and one counter uniform (key 6<<40),
+ * dt_event[g] = max(-ln(max(1e-12, u_g)) / totals[g], 1e-12); simulated time advances by n_executed[g] * dt_event[g]
+ * (n_executed summed over ranks; dt_event is the same on every rank).  res->np_used is 0.
  * Across ranks (cetkmc_create_rank*; needs (L / nranks) % box == 0): the boxes are sharded with the slabs -- D is the
  * number of THIS rank's boxes ((L / nranks / box) * (L / box)^2, global box order = rank order), events / n_executed /
  * res->nucleation_count cover this rank's boxes only (the caller sums them), totals are global.  Per super-step the
@@ -265,7 +278,7 @@ int cetkmc_stage_inputs(void* handle, const cetkmc_run_args* args);
  * send/recv, (L/box)^2 records each way): every rank applies its neighbours' boundary events to its own copy of the
  * halo planes and of the owned planes a diffusion target reached. */
 int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_result* res, double* totals,
-                          cetkmc_event* events, int64_t* n_executed);
+                          cetkmc_event* events, int64_t* n_executed, double* dt_event);
 
 int cetkmc_get_counters(void* handle, cetkmc_counters* out, int reset);
 

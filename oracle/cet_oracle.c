@@ -647,17 +647,32 @@ int64_t orc_run_steps(const orc_params *P, int L, int8_t *state, double *theta, 
  *     finite) is idle (event type -1).
  *   - uniforms are counter based: u(seed, g, key): pick KEY 1<<40 | d, theta 2<<40 | d, phi 3<<40 | d,
  *     defect 4<<40 | d, deposition species j*L + k (as Mode A rng_mode 1).
- *   - all picked events are applied (kmc_simulation.py:276-327 each), box order.
- * events: [n][D] (type -1 for idle boxes) or NULL; n_exec[n] = events applied per super-step. */
+ *   - null events (null_events != 0; Martinez et al., J. Comput. Phys. 227 (2008) 3804 "synchronous parallel KMC",
+ *     combined with the octant sublattices of Shim & Amar, Phys. Rev. B 71 (2005) 125432): "one event per box" alone
+ *     gives every non-idle box the same event frequency whatever its total rate R_d.  With R_max = the largest window
+ *     total of the super-step, box d executes its pick only if u_accept * R_max < R_d (u_accept = u(seed, g,
+ *     5<<40 | d)); otherwise the box performs a null event (logged as type -2, nothing applied).  An event e of an
+ *     active window then fires with probability r_e / R_max per visit -- proportional to its rate everywhere, as in
+ *     the reference's global pick (kmc_simulation.py:265-274).
+ *   - all accepted events are applied (kmc_simulation.py:276-327 each), box order.
+ *   - time advance: kmc_simulation.py:331-332 restated PER EXECUTED EVENT with the super-step's global total:
+ *     dt_event[g] = max(-ln(max(1e-12, u(seed, g, 6<<40))) / totals[g], 1e-12); simulated time advances by
+ *     n_exec[g] * dt_event[g].  (The reference advances time once per executed event by the same expression, and
+ *     its 1e-12 floor always binds at the rates of this model, so both modes report n_executed * 1e-12; where the
+ *     floor does not bind the mean is n_exec / total, the expected time for n_exec events of a process of rate
+ *     `total` -- and, with null events, 1 / (8 R_max) per super-step, the uniformised step of one octant visit.)
+ * events: [n][D] (type -1 idle box, -2 null event) or NULL; n_exec[n] = events applied per super-step. */
 #define KEY_PICK   (1ULL << 40)
 #define KEY_THETA  (2ULL << 40)
 #define KEY_PHI    (3ULL << 40)
 #define KEY_DEFECT (4ULL << 40)
+#define KEY_ACCEPT (5ULL << 40)
+#define KEY_DT     (6ULL << 40)
 
 static int window_select(const orc_params *P, int L, const int8_t *state, const double *theta,
                          const double *phi, const double *T, const int8_t *defects,
                          int i0, int j0, int k0, int H, double u, double *leaf, int32_t *lcnt,
-                         orc_event *ev)
+                         orc_event *ev, double *R_out)
 {
     const int PH = next_pow2(H), PT = next_pow2(3 * H);
     const int64_t NL = (int64_t)PT * PH * PH;
@@ -680,9 +695,11 @@ static int window_select(const orc_params *P, int L, const int8_t *state, const 
     ev->type = -1;                                   /* idle box: pos 0, target -1, rate 0 */
     ev->target[0] = ev->target[1] = ev->target[2] = -1;
     ev->dep_rank = -1;
+    if (R_out) *R_out = 0.0;
     if (n == 0) return 1;
     const double R = tree_sum(leaf, 0, NL, NL);
     if (R < 1e-25 || !isfinite(R)) return 1;
+    if (R_out) *R_out = R;
     const double r = u * R;
     double base = 0.0;
     const int64_t q = descend(leaf, NULL, lcnt, NL, NL, &base, r);
@@ -714,7 +731,7 @@ int orc_window_pick(const orc_params *P, int L, const int8_t *state, const doubl
     const int64_t NL = (int64_t)PT * PH * PH;
     double *leaf = (double *)malloc(sizeof(double) * (size_t)NL);
     int32_t *lcnt = (int32_t *)malloc(sizeof(int32_t) * (size_t)NL);
-    const int idle = window_select(P, L, state, theta, phi, T, defects, i0, j0, k0, H, u, leaf, lcnt, ev);
+    const int idle = window_select(P, L, state, theta, phi, T, defects, i0, j0, k0, H, u, leaf, lcnt, ev, NULL);
     free(leaf); free(lcnt);
     return idle;
 }
@@ -724,7 +741,7 @@ int64_t orc_run_supersteps(const orc_params *P, int L, int8_t *state, double *th
                            int64_t step0, int64_t n, int box, double defect_fraction, uint64_t seed,
                            int thermal_mode, double thermal_dt, const double *q_planes, int64_t *q_used,
                            double *totals, orc_event *events, int64_t *n_exec,
-                           int64_t *nuc_count, int *status)
+                           int64_t *nuc_count, int *status, int null_events, double *dt_event)
 {
     const int64_t nv = (int64_t)L * L * L;
     const int nb = L / box, H = (box == L) ? L : box / 2;
@@ -739,6 +756,7 @@ int64_t orc_run_supersteps(const orc_params *P, int L, int8_t *state, double *th
     double *leaf = (double *)malloc(sizeof(double) * (size_t)NL);
     int32_t *lcnt = (int32_t *)malloc(sizeof(int32_t) * (size_t)NL);
     orc_event *picked = (orc_event *)malloc(sizeof(orc_event) * (size_t)D);
+    double *Rd = (double *)malloc(sizeof(double) * (size_t)D);
     int64_t qpos = 0, s = 0;
     *status = 0;
     for (; s < n; ++s) {
@@ -759,6 +777,10 @@ int64_t orc_run_supersteps(const orc_params *P, int L, int8_t *state, double *th
         const double total = orc_total(L, blocksum, blockcnt, &ne, &nd);
         totals[s] = total;
         if (ne == 0 || total < 1e-25 || !isfinite(total)) { *status = 1; break; }
+        if (dt_event) {     /* kmc_simulation.py:331-332 per executed event, one draw per super-step */
+            const double u = orc_counter_uniform(seed, (uint64_t)g, KEY_DT);
+            dt_event[s] = pymax(-log(pymax(1e-12, u)) / total, 1e-12);
+        }
         const int sec = (int)(g % 8), si = (sec >> 2) & 1, sj = (sec >> 1) & 1, sk = sec & 1;
         /* select every box's event on the frozen lattice ... */
         for (int64_t d = 0; d < D; ++d) {
@@ -767,12 +789,18 @@ int64_t orc_run_supersteps(const orc_params *P, int L, int8_t *state, double *th
             const int j0 = (box == L) ? 0 : dj * box + sj * H;
             const int k0 = (box == L) ? 0 : dk * box + sk * H;
             const double u = orc_counter_uniform(seed, (uint64_t)g, KEY_PICK | (uint64_t)d);
-            window_select(P, L, state, theta, phi, T, defects, i0, j0, k0, H, u, leaf, lcnt, &picked[d]);
+            window_select(P, L, state, theta, phi, T, defects, i0, j0, k0, H, u, leaf, lcnt, &picked[d], &Rd[d]);
         }
-        /* ... then apply them all */
+        double Rmax = 0.0;
+        for (int64_t d = 0; d < D; ++d) if (picked[d].type >= 0 && Rd[d] > Rmax) Rmax = Rd[d];
+        /* ... then apply them all (null events: only the accepted ones) */
         int64_t ex = 0;
         for (int64_t d = 0; d < D; ++d) {
             orc_event *ev = &picked[d];
+            if (ev->type >= 0 && null_events) {
+                const double ua = orc_counter_uniform(seed, (uint64_t)g, KEY_ACCEPT | (uint64_t)d);
+                if (!(ua * Rmax < Rd[d])) ev->type = -2;      /* null event: the pick is logged, nothing is applied */
+            }
             if (events) events[s * D + d] = *ev;
             if (ev->type < 0) continue;
             if (ev->type == EV_DEP) {
@@ -793,7 +821,7 @@ int64_t orc_run_supersteps(const orc_params *P, int L, int8_t *state, double *th
         if (n_exec) n_exec[s] = ex;
     }
     if (q_used) *q_used = qpos;
-    free(rowsum); free(rowcnt); free(blocksum); free(blockcnt); free(Tn); free(leaf); free(lcnt); free(picked);
+    free(rowsum); free(rowcnt); free(blocksum); free(blockcnt); free(Tn); free(leaf); free(lcnt); free(picked); free(Rd);
     return s;
 }
 

@@ -270,10 +270,11 @@ class Lattice:
 
     # Mode B (not in the reference): synchronous super-steps over nb^3 boxes, see cet_oracle.c
     def run_supersteps(self, step0, n, box, defect_fraction, seed, thermal_mode=1, thermal_dt=1e-6, q_planes=None,
-                       want_events=True):
+                       want_events=True, null_events=False):
         L = self.L
         D = (L // box) ** 3
         totals = np.zeros(n, np.float64)
+        dt_event = np.zeros(n, np.float64)
         events = np.zeros((n, D), dtype=EVENT_DTYPE) if want_events else None
         n_exec = np.zeros(n, np.int64)
         q_used, nuc, status = C.c_int64(0), C.c_int64(self.nuc_count), C.c_int(0)
@@ -284,11 +285,11 @@ class Lattice:
             C.c_int64(step0), C.c_int64(n), int(box), C.c_double(defect_fraction), C.c_uint64(seed),
             int(thermal_mode), C.c_double(thermal_dt), _p(q, C.c_double), C.byref(q_used), _p(totals, C.c_double),
             events.ctypes.data_as(C.c_void_p) if want_events else None, _p(n_exec, C.c_int64), C.byref(nuc),
-            C.byref(status))
+            C.byref(status), int(bool(null_events)), _p(dt_event, C.c_double))
         self.nuc_count = nuc.value
         return dict(done=int(done), status=status.value, q_used=q_used.value,
                     totals=totals[:max(done, 0) + (1 if status.value == 1 else 0)],
-                    events=None if events is None else events[:done], n_exec=n_exec[:done])
+                    events=None if events is None else events[:done], n_exec=n_exec[:done], dt_event=dt_event[:done])
 
 
 def laser_source_plane(L, laser_pos, laser_power, beam_radius=50e-6, absorptivity=0.35):
@@ -304,7 +305,7 @@ def laser_source_plane(L, laser_pos, laser_power, beam_radius=50e-6, absorptivit
     return I_surface / VOXEL_SIZE
 
 
-KEY_PICK, KEY_THETA, KEY_PHI, KEY_DEFECT = 1 << 40, 2 << 40, 3 << 40, 4 << 40    # Mode B uniform keys
+KEY_PICK, KEY_THETA, KEY_PHI, KEY_DEFECT, KEY_ACCEPT, KEY_DT = (q << 40 for q in range(1, 7))    # Mode B uniform keys
 
 
 def set_threads(n):

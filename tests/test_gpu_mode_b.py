@@ -19,21 +19,26 @@ def _pair(oracle_mod, L, seed, fill, c, n_slabs=1):
     return e, lat
 
 
+@pytest.mark.parametrize("null_events", [False, True])
 @pytest.mark.parametrize("L,box,fill,n_slabs,df", [(16, 8, 0.2, 1, 0.05), (20, 10, 0.1, 2, 0.0), (32, 16, 0.3, 1, 0.1),
                                                   (24, 8, 0.02, 3, 0.02), (24, 12, 0.5, 1, 0.05)])
-def test_supersteps_vs_oracle(oracle_mod, L, box, fill, n_slabs, df):
+def test_supersteps_vs_oracle(oracle_mod, L, box, fill, n_slabs, df, null_events):
     e, lat = _pair(oracle_mod, L, 100 + L, fill, 0.2, n_slabs)
     step = 5
     for n in (19, 26):           # two batches: the second starts mid-cadence / mid-octant
-        rg = e.run_supersteps(step, n, box, df, seed=4242, thermal_mode=1, want_events=True)
-        ro = lat.run_supersteps(step, n, box, df, 4242, thermal_mode=1)
+        rg = e.run_supersteps(step, n, box, df, seed=4242, thermal_mode=1, want_events=True, null_events=null_events)
+        ro = lat.run_supersteps(step, n, box, df, 4242, thermal_mode=1, null_events=null_events)
         assert rg["done"] == ro["done"] == n and rg["status"] == ro["status"] == 0
         for f in ("type", "pos", "target", "atom"):
             assert np.array_equal(rg["events"][f], ro["events"][f]), f
-        live = ro["events"]["type"] >= 0
+        live = ro["events"]["type"] != -1           # executed picks and null events (type -2) both carry their rate
         assert relerr(rg["events"]["rate"][live], ro["events"]["rate"][live]).max() <= RATE_RTOL
         assert np.array_equal(rg["n_exec"], ro["n_exec"])
         assert relerr(rg["totals"], ro["totals"]).max() <= RATE_RTOL
+        # time advance (kmc_simulation.py:331-332 per executed event): host libm on both sides, totals within RATE_RTOL
+        assert relerr(rg["dt_event"], ro["dt_event"]).max() <= RATE_RTOL
+        if null_events:
+            assert (ro["events"]["type"] == -2).sum() > 0
         d = e.download()
         assert np.array_equal(d["state"], lat.state)
         assert np.array_equal(d["theta"], lat.theta) and np.array_equal(d["phi"], lat.phi)
@@ -81,10 +86,63 @@ def test_supersteps_argument_errors():
     e = cetkmc.Engine(24, impurity_c=0.1)
     st, th, ph, T, df = random_lattice(24, 1)
     e.upload(st, th, ph, T, df)
-    for box in (6, 9, 16, 24):
+    for box in (6, 9, 16, 48):
         with pytest.raises(RuntimeError):
             e.run_supersteps(0, 1, box, 0.0, seed=1)
     e.close()
+
+
+@pytest.mark.parametrize("L,fill,df,n_slabs,thermal_mode", [(8, 0.2, 0.1, 1, 1), (20, 0.05, 0.0, 2, 1), (33, 0.4, 0.05, 1, 2),
+                                                            (64, 0.1, 0.02, 1, 1)])
+def test_single_box_on_the_device_is_mode_a(oracle_mod, L, fill, df, n_slabs, thermal_mode):
+    """Device twin of tests/test_oracle_mode_b.py::test_single_box_is_mode_a: cetkmc_run_supersteps(box == L) -- one domain,
+    no octants -- equals cetkmc_run_steps (Mode A, kmc_simulation.py:246-332) fed the same counter uniforms, step by step:
+    events, totals, every field, nucleation count.  Both also equal the CPU comparator's single-box run (up to L = 33)."""
+    import cetkmc
+    from cetkmc import synthetic
+    n, seed, step0 = 45, 77, 3
+    state, theta, phi, T, defects = random_lattice(L, 5, fill=fill)
+    q = synthetic.laser_planes(L, step0, n) if thermal_mode == 2 else None
+
+    def engine():
+        e = cetkmc.Engine(L, impurity_c=0.2, n_slabs=n_slabs)
+        e.upload(state, theta, phi, T, defects)
+        e.set_prev_state(None)
+        return e
+    b = engine()
+    rb = b.run_supersteps(step0, n, L, df, seed, thermal_mode=thermal_mode, q_planes=q, want_events=True)
+    assert rb["done"] == n and np.all(rb["n_exec"] == 1) and rb["domains"] == 1
+    ev = rb["events"][:, 0]
+    u_pick = np.array([oracle_mod.counter_uniform(seed, step0 + s, oracle_mod.KEY_PICK) for s in range(n)])
+    u_def = np.array([oracle_mod.counter_uniform(seed, step0 + s, oracle_mod.KEY_DEFECT) for s in range(n)])
+    u_np = []
+    for s in range(n):
+        if ev["type"][s] in (0, 2):
+            u_np += [oracle_mod.counter_uniform(seed, step0 + s, oracle_mod.KEY_THETA),
+                     oracle_mod.counter_uniform(seed, step0 + s, oracle_mod.KEY_PHI)]
+    a = engine()
+    ra = a.run_steps(step0, n, df, u_pick, u_def, np.array(u_np + [0.0, 0.0]), rng_mode=1, seed=seed, thermal_mode=thermal_mode,
+                     q_planes=q)
+    assert ra["done"] == n and ra["np_used"] == len(u_np)
+    assert ra["events"].tobytes() == np.ascontiguousarray(ev).tobytes()          # the whole 64-byte records
+    assert np.array_equal(ra["totals"], rb["totals"])
+    da, db = a.download(), b.download()
+    for f in ("state", "theta", "phi", "T"):
+        assert np.array_equal(da[f], db[f]), f
+    assert a.nucleation_count() == b.nucleation_count()
+    # the all-counter stream through the Mode A entry point itself (rng_mode 2, no host streams)
+    c = engine()
+    rc = c.run_steps(step0, n, df, None, None, None, rng_mode=2, seed=seed, thermal_mode=thermal_mode, q_planes=q)
+    assert rc["events"].tobytes() == ra["events"].tobytes() and np.array_equal(rc["totals"], ra["totals"])
+    if L <= 33:
+        lat = oracle_mod.Lattice(state, theta, phi, T, defects, impurity_c=0.2)
+        ro = lat.run_supersteps(step0, n, L, df, seed, thermal_mode=thermal_mode, q_planes=q)
+        for f in ("type", "pos", "target", "atom"):
+            assert np.array_equal(ev[f], ro["events"][:, 0][f]), f
+        assert relerr(rb["totals"], ro["totals"]).max() <= RATE_RTOL and np.array_equal(db["state"], lat.state)
+        assert relerr(rb["dt_event"], ro["dt_event"]).max() <= RATE_RTOL
+    for x in (a, b, c):
+        x.close()
 
 
 def test_supersteps_full_size_properties(oracle_mod):

@@ -817,3 +817,99 @@ def test_staged_inputs_identical_and_checked():
         outs.append((r["totals"].tobytes(), r["events"].tobytes(), r["np_used"], {k: v.tobytes() for k, v in d.items()}))
         e.close()
     assert outs[0] == outs[1]
+
+
+def _fresh_engine(L, st, th, ph, T, df, n_slabs=1):
+    import cetkmc
+    e = cetkmc.Engine(L, impurity_c=0.2, n_slabs=n_slabs)
+    e.upload_planes(0, L, st, th, ph, T, df)
+    e.set_prev_state(None)
+    return e
+
+
+def _consumed_before(events, upto):
+    """rng_mode 1: doubles of u_np consumed by the first `upto` steps (2 per deposition / nucleation)"""
+    return int(2 * np.isin(events["type"][:upto], (0, 2)).sum())
+
+
+@pytest.mark.parametrize("thermal_mode,incremental,n_slabs", [(1, False, 1), (2, False, 2), (1, True, 1), (2, True, 1)])
+@pytest.mark.parametrize("stop_at", [25, 40, 60])
+def test_batch_that_runs_out_of_stream_continues_bit_identically(oracle_mod, thermal_mode, incremental, n_slabs, stop_at):
+    """A batch whose NumPy stream runs short stops with status 2; the steps still queued behind the stop run as
+    pass-throughs on the device while the host keeps flipping the temperature buffers and freshness flags.  The
+    continuation must (a) sweep from a rate table of the CURRENT field (stop_at = 25: an odd number -- one, step 40's --
+    of skipped temperature updates follow the stop; the table / deposition buffers are paired with the buffer parity) and
+    (b) not apply a temperature update twice when the stream ran out ON an update step (stop_at = 40, 60: the update of
+    that step ran before the selection noticed the shortage; kmc_simulation.py:248-250 updates T once per 20 steps).
+    Compared with one unbroken batch (bitwise: events, totals, every field) and with the oracle."""
+    from cetkmc import synthetic
+    L, n = 32, 50 if stop_at < 50 else 70
+    st, th, ph, T, df = synthetic.planes(L, 0, L, seed=13)
+    rs = np.random.RandomState(9)
+    u_pick, u_def, u_np = rs.random_sample(n), rs.random_sample(n), rs.random_sample(2 * n + 2)
+    q = synthetic.laser_planes(L, 0, n) if thermal_mode == 2 else None
+    kw = dict(rng_mode=1, seed=21, thermal_mode=thermal_mode, incremental=incremental)
+    ref = _fresh_engine(L, st, th, ph, T, df, n_slabs)
+    r0 = ref.run_steps(0, n, 0.05, u_pick, u_def, u_np, q_planes=q, **kw)
+    assert r0["done"] == n and r0["status"] == 0
+    d0 = ref.download_planes(0, L, state=True, theta=True, phi=True, T=True)
+    sweep0 = ref.rate_sweep()
+    ref.close()
+    # the same run, the first call given a stream that ends right before step `stop_at` needs its two orientation slots
+    cap = _consumed_before(r0["events"], stop_at) + 1
+    e = _fresh_engine(L, st, th, ph, T, df, n_slabs)
+    r1 = e.run_steps(0, n, 0.05, u_pick, u_def, u_np[:cap], q_planes=q, **kw)
+    assert r1["status"] == 2 and r1["done"] == stop_at and r1["np_used"] == cap - 1
+    q2 = synthetic.laser_planes(L, stop_at, n - stop_at) if thermal_mode == 2 else None
+    r2 = e.run_steps(stop_at, n - stop_at, 0.05, u_pick[stop_at:], u_def[stop_at:], u_np[r1["np_used"]:], q_planes=q2, **kw)
+    assert r2["status"] == 0 and r2["done"] == n - stop_at
+    assert np.concatenate([r1["events"], r2["events"]]).tobytes() == r0["events"].tobytes()
+    assert np.array_equal(np.concatenate([r1["totals"], r2["totals"]]), r0["totals"])
+    d1 = e.download_planes(0, L, state=True, theta=True, phi=True, T=True)
+    for f in d0:
+        assert np.array_equal(d0[f], d1[f]), f
+    assert e.rate_sweep() == sweep0
+    e.close()
+    lat = oracle_mod.Lattice(st.astype(np.int64), th, ph, T, df.astype(np.int64), impurity_c=0.2)
+    ro = lat.run_steps(0, n, 0.05, u_pick, u_def, u_np, rng_mode=1, seed=21, thermal_mode=thermal_mode, q_planes=q)
+    for f in ("type", "pos", "target", "atom"):
+        assert np.array_equal(r0["events"][f], ro["events"][f]), f
+    assert np.array_equal(d0["T"], lat.T) and np.array_equal(d0["state"], lat.state)
+
+
+def test_terminated_batch_leaves_a_consistent_engine(oracle_mod):
+    """status 1 (no valid events, kmc_simulation.py:260-262) in the middle of a batch: the queued rest passes through;
+    afterwards the rate sweep of the engine equals the oracle's on the same lattice, and stepping on after the caller has
+    made events possible again (a new temperature field) matches the oracle step by step."""
+    import cetkmc
+    L, n = 16, 70
+    # solid lattice with defects only (state 4: no events) except two vacancies whose neighbours are defects too:
+    # the only events are the vacancies' nucleations; once both are filled the run terminates
+    state = np.full((L, L, L), 4, np.int64)
+    state[3, 4, 5] = state[9, 9, 9] = 0
+    zeros = np.zeros((L, L, L))
+    T = np.full((L, L, L), 3000.0)
+    rs = np.random.RandomState(2)
+    u_pick, u_np = rs.random_sample(n), rs.random_sample(2 * n + 2)
+    e = cetkmc.Engine(L, impurity_c=0.2)
+    e.upload(state, zeros, zeros, T, None)
+    lat = oracle_mod.Lattice(state, zeros, zeros, T, None, impurity_c=0.2)
+    rg = e.run_steps(0, n, 0.0, u_pick, None, u_np, rng_mode=1, seed=1, thermal_mode=1)
+    ro = lat.run_steps(0, n, 0.0, u_pick, None, u_np, rng_mode=1, seed=1, thermal_mode=1)
+    assert rg["status"] == ro["status"] == 1 and rg["done"] == ro["done"] == 2
+    sw = lat.sweep()
+    assert e.rate_sweep() == (sw["total"], sw["n_events"], sw["n_dep"]) == (0.0, 0, 0)
+    d = e.download()
+    assert np.array_equal(d["state"], lat.state) and np.array_equal(d["T"], lat.T)
+    # open a few voxels again and continue: tables and interface sums must be those of the new state
+    s2 = lat.state.astype(np.int64).copy()
+    s2[5:8, 5:8, 5:8] = 0
+    s2[6, 6, 6] = 1
+    e.upload(s2, d["theta"], d["phi"], d["T"], None)
+    lat2 = oracle_mod.Lattice(s2, d["theta"], d["phi"], d["T"], None, impurity_c=0.2)
+    rg = e.run_steps(2, 20, 0.0, u_pick[2:], None, u_np, rng_mode=1, seed=1, thermal_mode=1)
+    ro = lat2.run_steps(2, 20, 0.0, u_pick[2:], None, u_np, rng_mode=1, seed=1, thermal_mode=1)
+    assert rg["done"] == ro["done"] == 20
+    for f in ("type", "pos", "target", "atom"):
+        assert np.array_equal(rg["events"][f], ro["events"][f]), f
+    e.close()

@@ -77,3 +77,74 @@ def test_oracle_threads_do_not_change_results(oracle_mod):
         outs.append((r["totals"].tobytes(), r["events"].tobytes(), lat.state.tobytes(), lat.T.tobytes()))
     oracle_mod.set_threads(1)
     assert outs[0] == outs[1]
+
+
+def test_time_advance_is_the_reference_formula_per_executed_event(oracle_mod):
+    """dt_event[g] = max(-ln(max(1e-12, u_g)) / totals[g], 1e-12) with u_g = u(seed, g, KEY_DT): kmc_simulation.py:331-332
+    restated per executed event (one draw per super-step).  At this model's rates the 1e-12 floor binds, as it does in every
+    reference trajectory; a cold lattice with tiny rates exercises the other branch."""
+    import math
+    lat = _lat(oracle_mod, 16, 4, 0.1)
+    r = lat.run_supersteps(7, 12, 8, 0.0, 99, thermal_mode=1)
+    for s in range(12):
+        u = oracle_mod.counter_uniform(99, 7 + s, oracle_mod.KEY_DT)
+        want = max(-math.log(max(1e-12, u)) / r["totals"][s], 1e-12)
+        assert r["dt_event"][s] == want
+    assert np.all(r["dt_event"] == 1e-12)
+    # a lattice whose total stays below 1e12 / s, where -ln(u) / total exceeds the floor: solid tungsten pointing "down"
+    # (theta = pi: attachment barrier E_b, kmc_event_rates.py:154), three isolated vacancies, 5 K below the melting point
+    # (no nucleation: dT <= DELTA_T_C, :120)
+    L = 8
+    state = np.ones((L, L, L), np.int64)
+    state[2, 3, 4] = state[5, 5, 1] = state[6, 1, 6] = 0
+    theta = np.where(state != 0, np.pi, 0.0)
+    slow = oracle_mod.Lattice(state, theta, np.zeros((L, L, L)), np.full((L, L, L), 3690.0), None, impurity_c=0.0)
+    rc = slow.run_supersteps(0, 3, 8, 0.0, 5, thermal_mode=0)
+    assert rc["done"] == 3 and rc["totals"].max() < 1e12
+    for s in range(3):
+        u = oracle_mod.counter_uniform(5, s, oracle_mod.KEY_DT)
+        assert rc["dt_event"][s] == -math.log(u) / rc["totals"][s] > 1e-12
+
+
+def test_null_events_accept_a_subset_of_the_picks(oracle_mod):
+    """null_events: the picks of the first super-step are those of the plain mode (same frozen lattice, same uniforms);
+    the accepted ones are a subset, the others are logged as type -2 with the same voxel and rate; the single-box case
+    (R_d == R_max) accepts everything, so it stays Mode A."""
+    a, b = _lat(oracle_mod, 16, 9, 0.3), _lat(oracle_mod, 16, 9, 0.3)
+    ra = a.run_supersteps(0, 1, 8, 0.0, 11, thermal_mode=1)
+    rb = b.run_supersteps(0, 1, 8, 0.0, 11, thermal_mode=1, null_events=True)
+    ea, eb = ra["events"][0], rb["events"][0]
+    assert np.array_equal(ea["pos"], eb["pos"]) and np.array_equal(ea["rate"], eb["rate"])
+    assert set(np.unique(eb["type"])) <= {-2, -1, 0, 1, 2, 3}
+    live = eb["type"] >= 0
+    assert np.array_equal(ea["type"][live], eb["type"][live]) and np.all(ea["type"][eb["type"] == -2] >= 0)
+    assert np.array_equal(ea["type"] == -1, eb["type"] == -1)
+    assert rb["n_exec"][0] == live.sum() >= 1                      # the box holding R_max always executes
+    assert np.array_equal(ra["dt_event"], rb["dt_event"])
+    one_a, one_b = _lat(oracle_mod, 10, 2, 0.2), _lat(oracle_mod, 10, 2, 0.2)
+    r1 = one_a.run_supersteps(0, 30, 10, 0.05, 3, thermal_mode=1)
+    r2 = one_b.run_supersteps(0, 30, 10, 0.05, 3, thermal_mode=1, null_events=True)
+    assert r1["events"].tobytes() == r2["events"].tobytes() and np.array_equal(one_a.state, one_b.state)
+
+
+def test_null_events_acceptance_follows_the_window_rate(oracle_mod):
+    """Boxes 0..3 (planes 0..7) hold ONE empty voxel per active window among defects (state 4: no events), boxes 4..7 are
+    empty: at constant temperature every empty voxel owns the same nucleation rate r, so R_d = r in the sparse boxes and
+    64 r in the empty ones (= R_max, always accepted).  The sparse boxes must execute with probability 1/64."""
+    L, box = 16, 8
+    state = np.zeros((L, L, L), np.int64)
+    state[:8] = 4
+    for dj in range(2):
+        for dk in range(2):
+            state[1, dj * 8 + 2, dk * 8 + 1] = 0            # inside the octant-0 window of boxes (0, dj, dk)
+    zeros = np.zeros((L, L, L))
+    T = np.full((L, L, L), 3000.0)
+    hits, trials = 0, 0
+    for seed in range(160):
+        lat = oracle_mod.Lattice(state, zeros, zeros, T, None, impurity_c=0.0)
+        r = lat.run_supersteps(0, 1, box, 0.0, seed, thermal_mode=0, null_events=True)
+        t = r["events"][0]["type"]
+        assert np.all(t[4:] >= 0) and np.all(t[:4] != -1)    # empty boxes always execute; sparse boxes always pick
+        hits += int((t[:4] >= 0).sum())
+        trials += 4
+    assert trials == 640 and 2 <= hits <= 25                 # binomial(640, 1/64): mean 10, sigma 3.1

@@ -1,0 +1,82 @@
+"""Mode B vs Mode A at equal executed-event counts (tests/test_gpu_mode_b_product.py uses collect(); run as a script for a table).
+
+For every seed: run_kmc(mode="B") for ~n_events executed events, then run_kmc(mode="A") for EXACTLY the number of events
+Mode B executed, same seed (same initial lattice: initialize_lattice is seeded by `seed` in both).  Returns the last
+metrics row of both runs per seed.
+
+    python tools/mode_b_stats.py [--L 64] [--events 60000] [--seeds 8] [--box 8] [--no-null] [--cadence events]
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pandas as pd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "cet-driven-simulation-for-3d-printing-am-kmc-approach_amd"))
+
+COLS = ("Step", "AspectRatio", "EquiaxedFraction", "GrainCount", "AvgGrainSize", "W_Count", "Re_Count", "C_Count",
+        "NucleationCount", "DefectDensity", "CET_Class", "Time")
+
+
+def collect(L=64, n_events=60000, seeds=range(8), box=8, null_events=True, thermal_cadence="events", impurity_c=0.1,
+            defect_fraction=3e-3, n_seeds=20, metrics_every=None, quiet=True):
+    import contextlib
+    import io
+
+    import kmc_simulation
+    me = metrics_every or max(200, n_events // 4)
+    out = []
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            for seed in seeds:
+                rows = {}
+                n_a = n_events
+                for mode in ("B", "A"):
+                    kw = dict(L=L, n_steps=n_a, defect_fraction=defect_fraction, n_seeds=n_seeds, impurity_c=impurity_c,
+                              output_prefix=f"stat_{mode}_{seed}", seed=seed, metrics_every=me)
+                    if mode == "B":
+                        kw.update(mode="B", box=box, null_events=null_events, thermal_cadence=thermal_cadence)
+                    with contextlib.redirect_stdout(io.StringIO() if quiet else sys.stdout):
+                        kmc_simulation.run_kmc(**kw)
+                    last = pd.read_csv(f"outputs/stat_{mode}_{seed}/metrics.csv").iloc[-1]
+                    rows[mode] = {c: (last[c].item() if hasattr(last[c], "item") else last[c]) for c in COLS}
+                    if mode == "B":
+                        n_a = int(last["Step"]) + 1            # Mode A executes exactly what Mode B executed
+                assert rows["A"]["Step"] == rows["B"]["Step"]
+                out.append(dict(seed=seed, **{f"{k}_{m}": v for m in "AB" for k, v in rows[m].items()}))
+        finally:
+            os.chdir(cwd)
+    return out
+
+
+def summarize(rows):
+    t = {}
+    for c in COLS:
+        if c in ("CET_Class",):
+            t[c] = dict(A=[r[c + "_A"] for r in rows], B=[r[c + "_B"] for r in rows])
+            continue
+        a = np.array([r[c + "_A"] for r in rows], float)
+        b = np.array([r[c + "_B"] for r in rows], float)
+        t[c] = dict(mean_A=a.mean(), mean_B=b.mean(), sd_A=a.std(ddof=1) if len(a) > 1 else 0.0,
+                    sd_B=b.std(ddof=1) if len(b) > 1 else 0.0, rel_diff=(b.mean() - a.mean()) / a.mean() if a.mean() else 0.0)
+    return t
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--L", type=int, default=64)
+    ap.add_argument("--events", type=int, default=60000)
+    ap.add_argument("--seeds", type=int, default=8)
+    ap.add_argument("--box", type=int, default=8)
+    ap.add_argument("--no-null", action="store_true")
+    ap.add_argument("--cadence", default="events")
+    ap.add_argument("--carbon", type=float, default=0.1)
+    a = ap.parse_args()
+    rows = collect(a.L, a.events, range(a.seeds), a.box, not a.no_null, a.cadence, impurity_c=a.carbon)
+    print(json.dumps(dict(args=vars(a), summary=summarize(rows), rows=rows), indent=1, default=str))
