@@ -39,7 +39,7 @@ THERMAL_DT = 1e-6           # kmc_simulation.py:250
 _MAX_STREAM_DOUBLES = 1 << 25   # host staging cap for the pre-drawn NumPy stream (256 MiB)
 
 
-def _advance_to(engine, first, last, L, defect_fraction, rng_mode=0, seed=0, incremental=True):
+def _advance_to(engine, first, last, L, defect_fraction, rng_mode=0, seed=0, incremental=True, thermal_mode=1):
     """Run steps first..last (inclusive) on the device.  Returns (steps_done, terminated,
     last_total, dt_sum_increments) with both host generators left where the reference's would be."""
     dts = []
@@ -65,7 +65,7 @@ def _advance_to(engine, first, last, L, defect_fraction, rng_mode=0, seed=0, inc
         np_state = np.random.get_state()
         u_np = np.random.random(n * per_step)
         res = engine.run_steps(step, n, defect_fraction, draws[:, 0], draws[:, 1] if per == 3 else None, u_np,
-                               rng_mode=rng_mode, seed=seed, thermal_mode=1, thermal_dt=THERMAL_DT,
+                               rng_mode=rng_mode, seed=seed, thermal_mode=thermal_mode, thermal_dt=THERMAL_DT,
                                incremental=incremental)
         done = res["done"]
         # rewind both generators to what the executed steps consumed
@@ -141,6 +141,7 @@ def run_kmc(
     thermal_cadence: str = "events",
     seed: int = None,
     metrics_every: int = METRIC_UPDATE_STEP,
+    thermal_updates: bool = True,
 ):
     """KMC microstructure evolution with natural defect injection (same contract as the
     reference).  ``defect_fraction`` is the per-event probability that the just-updated voxel
@@ -154,7 +155,9 @@ def run_kmc(
     ``nu_dep`` overrides constants.NU_DEP (deposition attempt frequency = growth velocity V of the G-V sweep
     driver gv_sweep.py; the reference can only change it by editing constants.py);
     ``seed`` replaces constants.RANDOM_SEED for both host generators (and keys Mode B's counter uniforms);
-    ``metrics_every`` replaces constants.METRIC_UPDATE_STEP (cadence of the metrics rows and of the defect-mask refresh).
+    ``metrics_every`` replaces constants.METRIC_UPDATE_STEP (cadence of the metrics rows and of the defect-mask refresh);
+    ``thermal_updates=False`` keeps the initial temperature field (no update_temperature_cet calls: a stationary
+    environment, used to compare the two stepping modes without the reference's event-count thermal clock).
 
     ``mode="B"``: synchronous super-steps over ``(L/box)**3`` boxes (cetkmc_run_supersteps; ``box == L`` is the
     single-domain case = the exact loop with counter uniforms).  ``n_steps`` keeps its meaning -- the number of EXECUTED
@@ -271,7 +274,8 @@ def run_kmc(
         stop = min(stop, n_steps - 1)
         if checkpoint_every > 0:      # also stop right before every checkpoint boundary
             stop = min(stop, (next_step // checkpoint_every + 1) * checkpoint_every - 1)
-        done, terminated, last_total, dts = _advance_to(engine, next_step, stop, L, defect_fraction, incremental=incremental)
+        done, terminated, last_total, dts = _advance_to(engine, next_step, stop, L, defect_fraction, incremental=incremental,
+                                                         thermal_mode=1 if thermal_updates else 0)
         for dt in dts:
             total_time += dt
         if terminated:
@@ -300,7 +304,7 @@ def run_kmc(
         nbx = L // box if (box and L % box == 0) else 1
         d_max = 1 if box == L else nbx ** 3                       # events per super-step at most
         executed, g, thermal_done = 0, 0, 0
-        by_events = thermal_cadence == "events"
+        by_events = thermal_cadence == "events" and thermal_updates
         while executed < n_steps:
             # super-steps until (at the earliest) the next metrics boundary / the end: a super-step executes <= d_max events
             # (a row is due once executed - 1 reaches the next multiple of metrics_every)
@@ -314,7 +318,7 @@ def run_kmc(
                 for _ in range(due - thermal_done):
                     engine.thermal_cet(THERMAL_DT, scrub_nan=True)
                 thermal_done = due
-            r = engine.run_supersteps(g, nb, box, defect_fraction, run_seed, thermal_mode=0 if by_events else 1,
+            r = engine.run_supersteps(g, nb, box, defect_fraction, run_seed, thermal_mode=0 if (by_events or not thermal_updates) else 1,
                                       thermal_dt=THERMAL_DT, null_events=null_events)
             before = executed
             for s in range(r["done"]):

@@ -23,7 +23,7 @@ COLS = ("Step", "AspectRatio", "EquiaxedFraction", "GrainCount", "AvgGrainSize",
 
 
 def collect(L=64, n_events=60000, seeds=range(8), box=8, null_events=True, thermal_cadence="events", impurity_c=0.1,
-            defect_fraction=3e-3, n_seeds=20, metrics_every=None, quiet=True):
+            defect_fraction=3e-3, n_seeds=20, metrics_every=None, quiet=True, thermal_updates=True):
     import contextlib
     import io
 
@@ -39,7 +39,7 @@ def collect(L=64, n_events=60000, seeds=range(8), box=8, null_events=True, therm
                 n_a = n_events
                 for mode in ("B", "A"):
                     kw = dict(L=L, n_steps=n_a, defect_fraction=defect_fraction, n_seeds=n_seeds, impurity_c=impurity_c,
-                              output_prefix=f"stat_{mode}_{seed}", seed=seed, metrics_every=me)
+                              output_prefix=f"stat_{mode}_{seed}", seed=seed, metrics_every=me, thermal_updates=thermal_updates)
                     if mode == "B":
                         kw.update(mode="B", box=box, null_events=null_events, thermal_cadence=thermal_cadence)
                     with contextlib.redirect_stdout(io.StringIO() if quiet else sys.stdout):
@@ -77,6 +77,8 @@ if __name__ == "__main__":
     ap.add_argument("--no-null", action="store_true")
     ap.add_argument("--cadence", default="events")
     ap.add_argument("--carbon", type=float, default=0.1)
+    ap.add_argument("--no-thermal", action="store_true")
     a = ap.parse_args()
-    rows = collect(a.L, a.events, range(a.seeds), a.box, not a.no_null, a.cadence, impurity_c=a.carbon)
+    rows = collect(a.L, a.events, range(a.seeds), a.box, not a.no_null, a.cadence, impurity_c=a.carbon,
+                   thermal_updates=not a.no_thermal)
     print(json.dumps(dict(args=vars(a), summary=summarize(rows), rows=rows), indent=1, default=str))
