@@ -64,7 +64,8 @@ class Counters(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("steps", "sweeps", "incremental_steps", "thermal_updates", "supersteps", "bytes_h2d",
                                          "bytes_d2h", "alg_bytes_sweep", "alg_bytes_thermal", "profiled_steps")] + \
                [(n, C.c_double) for n in ("ms_thermal", "ms_interface", "ms_sweep", "ms_dirty_rows", "ms_reduce", "ms_select_apply")] + \
-               [(n, C.c_int64) for n in ("alg_bytes_table", "table_updates", "interface_launches")]
+               [(n, C.c_int64) for n in ("alg_bytes_table", "table_updates", "interface_launches")] + \
+               [("ms_comm", C.c_double), ("comm_calls", C.c_int64)]
 
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
@@ -79,7 +80,7 @@ class RunResult(C.Structure):
     _fields_ = [
         ("steps_done", C.c_int64), ("status", C.c_int32), ("np_used", C.c_int64), ("q_used", C.c_int64),
         ("nucleation_count", C.c_int64), ("sweep_ms_total", C.c_double), ("sweep_launches", C.c_int64),
-        ("wall_ms", C.c_double), ("full_sweeps", C.c_int64),
+        ("wall_ms", C.c_double), ("full_sweeps", C.c_int64), ("min_margin", C.c_double),
     ]
 
 

@@ -279,7 +279,8 @@ class Engine:
         done = res.steps_done
         out = dict(done=int(done), status=int(res.status), np_used=int(res.np_used), q_used=int(res.q_used),
                    nucleation_count=int(res.nucleation_count), sweep_ms_total=res.sweep_ms_total,
-                   sweep_launches=int(res.sweep_launches), wall_ms=res.wall_ms, full_sweeps=int(res.full_sweeps))
+                   sweep_launches=int(res.sweep_launches), wall_ms=res.wall_ms, full_sweeps=int(res.full_sweeps),
+                   min_margin=float(res.min_margin))
         if want_logs:
             out.update(totals=totals[:done + (1 if res.status == 1 else 0)], events=events[:done], n_events=nev[:done])
         return out

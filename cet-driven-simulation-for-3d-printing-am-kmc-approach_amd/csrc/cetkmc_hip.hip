@@ -150,6 +150,11 @@ struct Handle {
     std::vector<int> cc_roots_sorted;
     std::vector<hipEvent_t> prof;
     cetkmc_host_comm hc{};       // host-relay transport (cetkmc_create_rank_host); used when comm is null
+    // profile 2: every collective of the batch is bracketed by a hipEvent pair on the stream (RCCL: the collective's own
+    // device time; host relay: copies + callback + the synchronisations around them)
+    bool time_comm = false;
+    std::vector<hipEvent_t> comm_ev;
+    size_t comm_ev_used = 0;
     std::vector<char> hc_stage;
     cetkmc_counters cnt{};       // cetkmc_get_counters: work issued / bytes moved / per-phase device time
     // look-ahead temperature update: T(n+1) + its rate table computed on stream2 while the 19 steps between two updates run
@@ -552,8 +557,17 @@ int refresh_ifc_grid(Handle* h)
 // ---- collectives: RCCL on the stream, or relayed through host callbacks (bring-up / test transport) ------
 inline bool multi_rank(const Handle* h) { return h->comm != nullptr || h->hc.allgather != nullptr; }
 
+// profile 2: one more hipEvent of the batch's collective timers, recorded on the stream now (nullptr when not timing)
+int comm_stamp(Handle* h)
+{
+    if (!h->time_comm) return 0;
+    if (h->comm_ev_used == h->comm_ev.size()) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->comm_ev.push_back(e); }
+    HIPCHK(hipEventRecord(h->comm_ev[h->comm_ev_used++], h->stream));
+    return 0;
+}
+
 // in-place all-gather of `per` bytes per rank inside the device buffer `buf` (rank r's part at buf + r*per)
-int comm_allgather(Handle* h, void* buf, size_t per)
+int comm_allgather_raw(Handle* h, void* buf, size_t per)
 {
     if (h->comm) {
         NCCLCHK(g_rccl.AllGather((const char*)buf + per * h->rank, buf, per, ncclChar, h->comm, h->stream));
@@ -568,6 +582,12 @@ int comm_allgather(Handle* h, void* buf, size_t per)
     HIPCHK(hipMemcpyAsync(buf, host, per * h->nranks, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
+}
+int comm_allgather(Handle* h, void* buf, size_t per)
+{
+    CHK(comm_stamp(h));
+    CHK(comm_allgather_raw(h, buf, per));
+    return comm_stamp(h);
 }
 
 // Incremental step (run_steps with incremental = 1, between temperature updates): only the rows the
@@ -696,7 +716,15 @@ int launch_select_apply(Handle* h, const BatchCfg& cfg, int eval_touched, int* d
 
 // neighbour exchange along the slab axis: `bytes` from send_lo to rank-1 / send_hi to rank+1 (device pointers), the
 // neighbours' counterparts into recv_lo / recv_hi.  End ranks skip the missing side (its recv buffer is left alone).
+int comm_exchange_raw(Handle* h, const void* send_lo, void* recv_lo, const void* send_hi, void* recv_hi, size_t bytes);
 int comm_exchange(Handle* h, const void* send_lo, void* recv_lo, const void* send_hi, void* recv_hi, size_t bytes)
+{
+    if (h->nranks <= 1) return 0;
+    CHK(comm_stamp(h));
+    CHK(comm_exchange_raw(h, send_lo, recv_lo, send_hi, recv_hi, bytes));
+    return comm_stamp(h);
+}
+int comm_exchange_raw(Handle* h, const void* send_lo, void* recv_lo, const void* send_hi, void* recv_hi, size_t bytes)
 {
     if (h->nranks <= 1) return 0;
     const bool lo = h->rank > 0, hi = h->rank < h->nranks - 1;
@@ -911,6 +939,7 @@ void destroy_impl(Handle* h)
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     for (auto e : h->prof) (void)hipEventDestroy(e);
+    for (auto e : h->comm_ev) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_main) (void)hipEventDestroy(h->ev_main);
@@ -1415,6 +1444,8 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
     auto pev = [&](int64_t s, int q) -> hipEvent_t { return a->profile == 2 ? h->prof[EPS * s + q] : nullptr; };
     std::vector<char> was_thermal, was_full;
     if (a->profile == 2) { was_thermal.assign((size_t)n, 0); was_full.assign((size_t)n, 0); }
+    h->time_comm = a->profile == 2 && multi_rank(h);
+    h->comm_ev_used = 0;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     int64_t q_idx = 0;
     const bool incr = a->incremental && h->sweep_variant >= 1;
@@ -1487,8 +1518,18 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
     if (n_events && n > 0) memcpy(n_events, h->pin_out + o_nev, (size_t)n * 8);
     if (nsl) memcpy(list_len.data(), h->pin_out + o_len, nsl * sizeof(int));
     if (h->spec.valid) { HIPCHK(hipStreamSynchronize(h->stream2)); h->spec.valid = false; }      // never outlives its batch
+    if (h->time_comm) {
+        for (size_t q = 0; q + 1 < h->comm_ev_used; q += 2) {
+            float t = 0.f;
+            HIPCHK(hipEventElapsedTime(&t, h->comm_ev[q], h->comm_ev[q + 1]));
+            h->cnt.ms_comm += t;
+            ++h->cnt.comm_calls;
+        }
+        h->time_comm = false; h->comm_ev_used = 0;
+    }
     res->steps_done = ss.cur; res->status = ss.status; res->np_used = ss.np_pos; res->q_used = q_idx;
     res->nucleation_count = ss.nuc_count;
+    res->min_margin = ss.min_margin;
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     res->wall_ms = ms;
@@ -1655,7 +1696,7 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
     StepState ss;
     HIPCHK(hipMemcpyAsync(&ss, h->d_ss, sizeof ss, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    ss.cur = 0; ss.status = 0; ss.np_pos = 0; ss.q_pos = 0;
+    ss.cur = 0; ss.status = 0; ss.np_pos = 0; ss.min_margin = 1.0;
     HIPCHK(hipMemcpyAsync(h->d_ss, &ss, sizeof ss, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     BatchCfg cfg{};
@@ -1717,7 +1758,7 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
     res->nucleation_count = ss.nuc_count;
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    res->wall_ms = ms; res->sweep_ms_total = 0.0; res->sweep_launches = 0; res->full_sweeps = n;
+    res->wall_ms = ms; res->sweep_ms_total = 0.0; res->sweep_launches = 0; res->full_sweeps = n; res->min_margin = 1.0;
     h->cnt.supersteps += ss.cur;
     if (ss.status != 0) { h->table_fresh = false; h->ifc_fresh = false; h->swept = false; }     // as in cetkmc_run_steps
     CHK(refresh_ifc_grid(h));

@@ -33,7 +33,7 @@ struct StepState {
     double  total;      // last sweep
     int64_t n_events;
     int64_t n_dep;
-    int64_t q_pos;
+    double  min_margin; // batch: smallest distance of a pick r from the boundaries of the chosen event's interval, / total
 };
 
 struct BatchCfg {
@@ -850,8 +850,10 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
     double u0 = 0.0, u_def = 0.0, u_th = 0.0, u_ph = 0.0;
     long long np_pos0 = 0, cur = 0, nuc0 = 0;
     int status0 = 0;
+    double margin0 = 1.0;
     if (tid == 0 && cfg.batch) {
         status0 = ss->status;
+        margin0 = ss->min_margin;
         np_pos0 = ss->np_pos;
         nuc0 = ss->nuc_count;
         cur = cur_hint >= 0 ? cur_hint : ss->cur;
@@ -1025,7 +1027,7 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
         }
         // slot scan (kmc_simulation.py:268-274 restricted to this voxel's slots)
         int p_type = -1, p_m = -1, p_atom = 0;
-        double p_rate = 0.0;
+        double p_rate = 0.0, p_cum = 0.0;          // p_cum: running sum including the chosen event
         const int lc = voxcnt_l[k];
         if ((lc & 255) == 1 && (c == CAT_DEP || (c == CAT_EMPTY && !(lc >> 8)))) {
             // a single event whose kind is known without looking again: the deposition of this voxel, or the nucleation
@@ -1033,6 +1035,7 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
             p_type = (c == CAT_DEP) ? EV_DEP : EV_NUC;
             p_atom = (c == CAT_DEP) ? 0 : 1;
             p_rate = leafval[k];
+            p_cum = base + p_rate;
         } else {
             const int st = S.state[S.sidx(li, j, k)];
             double cum = base;
@@ -1042,9 +1045,19 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
                 if (cat != c || found) return;
                 cum += rate;
                 p_type = type; p_m = m; p_atom = atom; p_rate = rate;   // remembers the last valid slot
+                p_cum = cum;
                 if (cum >= r) found = true;
             };
             eval_voxel(P, S, ktab, li, i, j, k, st, S.T[S.tidx(li, j, k)], nb, emit);
+        }
+        if (cfg.batch) {
+            // Selection margin (hard part 3): r lies in the chosen event's interval (p_cum - rate, p_cum] of
+            // the canonical cumulative sum; the reference scans a sequentially rounded sum (kmc_simulation.py:265-274) that
+            // differs by ~1e-13 relative, so a pick closer than that to either end of the interval could be the neighbouring
+            // event there.  The batch reports the smallest such distance relative to the total.
+            const double lo = r - (p_cum - p_rate), hi = p_cum - r;
+            const double m = (fabs(lo) < fabs(hi) ? fabs(lo) : fabs(hi)) / ta.total;
+            if (m < margin0) ss->min_margin = m;
         }
         cetkmc_event ev;
         ev.type = p_type;
@@ -1589,7 +1602,7 @@ __global__ void k_empty() {}
 // start of a batch: the batch part of the step state (nucleation_count persists) -- on the stream, no host round trip
 __global__ void k_batch_reset(StepState* ss)
 {
-    ss->cur = 0; ss->status = 0; ss->np_pos = 0; ss->q_pos = 0;
+    ss->cur = 0; ss->status = 0; ss->np_pos = 0; ss->min_margin = 1.0;
 }
 
 // ---- thermal -------------------------------------------------------------------------------

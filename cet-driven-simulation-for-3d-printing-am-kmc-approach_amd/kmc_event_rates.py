@@ -16,16 +16,45 @@ _OFFSETS = np.array(
     [(1, 1, 0), (1, -1, 0), (-1, 1, 0), (-1, -1, 0), (0, 1, 1), (0, 1, -1), (0, -1, 1), (0, -1, -1),
      (2, 0, 0), (-2, 0, 0), (0, 2, 0), (0, -2, 0), (0, 0, 2), (0, 0, -2)], dtype=np.int64)
 
-_engines = {}
+class _EngineCache:
+    """Device lattices kept between calls of the pure-function drop-ins, least recently used first out: at most
+    ``max_engines`` handles (a 256^3 handle owns ~1.3 GB of HBM); ``close_engines()`` releases them all."""
+
+    def __init__(self, max_engines=2):
+        from collections import OrderedDict
+        self.max_engines = max_engines
+        self._d = OrderedDict()
+
+    def get(self, L, make):
+        eng = self._d.pop(L, None)
+        if eng is None:
+            while len(self._d) >= self.max_engines:
+                self._d.popitem(last=False)[1].close()
+            eng = make()
+        self._d[L] = eng
+        return eng
+
+    def close(self):
+        while self._d:
+            self._d.popitem()[1].close()
+
+    def __len__(self):
+        return len(self._d)
+
+
+_engines = _EngineCache()
+
+
+def close_engines():
+    """Release the cached device lattices of this module."""
+    _engines.close()
 
 
 def _engine(L, impurity_c):
-    """One cached device lattice per edge length (handles are reused across calls)."""
+    """One cached device lattice per edge length (handles are reused across calls; bounded, see _EngineCache)."""
     import cetkmc
-    eng = _engines.get(L)
-    if eng is None:
-        eng = _engines[L] = cetkmc.Engine(L, impurity_c=impurity_c)
-    elif eng.params.impurity_c != float(impurity_c):
+    eng = _engines.get(L, lambda: cetkmc.Engine(L, impurity_c=impurity_c))
+    if eng.params.impurity_c != float(impurity_c):
         eng.set_impurity_c(impurity_c)
     return eng
 

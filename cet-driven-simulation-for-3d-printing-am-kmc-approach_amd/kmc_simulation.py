@@ -34,6 +34,14 @@ from metrics import compute_CET, compute_metrics, compute_metrics_device, detect
 from constants import CET_AR_THRESHOLD, CET_EQ_THRESHOLD
 from thermal_solver import update_temperature_cet as update_temperature  # noqa: F401
 
+# What the last run_kmc call observed besides its return tuple (the reference's signature has no room for it):
+#   min_margin  smallest selection margin of the run (cetkmc_run_result.min_margin: distance of r = u * total from the nearer
+#               end of the chosen event's interval of the cumulative rate sum, relative to the total).  The device sums rates by
+#               a balanced tree, the reference left to right (kmc_simulation.py:259,265-274); the two sums differ by <= ~1e-13
+#               relative, so only a pick with a margin below MARGIN_WARN could have gone to the neighbouring event there.
+last_run_info = {}
+MARGIN_WARN = 1e-12
+
 THERMAL_EVERY = 20          # kmc_simulation.py:248
 THERMAL_DT = 1e-6           # kmc_simulation.py:250
 _MAX_STREAM_DOUBLES = 1 << 25   # host staging cap for the pre-drawn NumPy stream (256 MiB)
@@ -43,6 +51,7 @@ def _advance_to(engine, first, last, L, defect_fraction, rng_mode=0, seed=0, inc
     """Run steps first..last (inclusive) on the device.  Returns (steps_done, terminated,
     last_total, dt_sum_increments) with both host generators left where the reference's would be."""
     dts = []
+    _advance_to.min_margin = 1.0
     step = first
     terminated = False
     last_total = 0.0
@@ -68,6 +77,7 @@ def _advance_to(engine, first, last, L, defect_fraction, rng_mode=0, seed=0, inc
                                rng_mode=rng_mode, seed=seed, thermal_mode=thermal_mode, thermal_dt=THERMAL_DT,
                                incremental=incremental)
         done = res["done"]
+        _advance_to.min_margin = min(_advance_to.min_margin, res["min_margin"])
         # rewind both generators to what the executed steps consumed
         np.random.set_state(np_state)
         if res["np_used"]:
@@ -211,6 +221,7 @@ def run_kmc(
         raise ValueError("mode 'B': box must be even, 8..16, and divide L (or equal L: single domain)")
 
     total_time = 0.0
+    min_margin = 1.0
     metrics_data = []
     cet_detected = False
     step = -1
@@ -278,6 +289,7 @@ def run_kmc(
                                                          thermal_mode=1 if thermal_updates else 0)
         for dt in dts:
             total_time += dt
+        min_margin = min(min_margin, _advance_to.min_margin)
         if terminated:
             step = next_step + done
             print(f"Terminating at step {step}: no valid events (rate={last_total:.2e})")
@@ -347,5 +359,10 @@ def run_kmc(
     state, theta, phi = fields["state"], fields["theta"], fields["phi"]
     atom_type = state.copy()
     engine.close()
+    last_run_info.clear()
+    last_run_info.update(mode=mode, min_margin=min_margin if mode == "A" else None, executed_events=step + 1)
+    if mode == "A" and min_margin < MARGIN_WARN:
+        print(f"Note: smallest selection margin {min_margin:.2e} < {MARGIN_WARN:.0e} of the total rate -- a pick this close to an "
+              "event boundary may differ from the reference's sequential scan")
     print(f"Completed {step + 1} steps in {total_time:.2e} s")
     return state, atom_type, total_time, theta, phi

@@ -16,15 +16,43 @@ ALPHA = K / (RHO * CP)
 DEFAULT_BEAM_RADIUS = 50e-6
 DEFAULT_ABSORPTIVITY = 0.35
 
-_engines = {}
+class _EngineCache:
+    """Device lattices kept between calls of the pure-function drop-ins, least recently used first out: at most
+    ``max_engines`` handles (a 256^3 handle owns ~1.3 GB of HBM); ``close_engines()`` releases them all."""
+
+    def __init__(self, max_engines=2):
+        from collections import OrderedDict
+        self.max_engines = max_engines
+        self._d = OrderedDict()
+
+    def get(self, L, make):
+        eng = self._d.pop(L, None)
+        if eng is None:
+            while len(self._d) >= self.max_engines:
+                self._d.popitem(last=False)[1].close()
+            eng = make()
+        self._d[L] = eng
+        return eng
+
+    def close(self):
+        while self._d:
+            self._d.popitem()[1].close()
+
+    def __len__(self):
+        return len(self._d)
+
+
+_engines = _EngineCache()
+
+
+def close_engines():
+    """Release the cached device lattices of this module."""
+    _engines.close()
 
 
 def _engine(L):
     import cetkmc
-    eng = _engines.get(L)
-    if eng is None:
-        eng = _engines[L] = cetkmc.Engine(L)
-    return eng
+    return _engines.get(L, lambda: cetkmc.Engine(L))
 
 
 def build_temperature_field(L=None):

@@ -121,6 +121,11 @@ typedef struct cetkmc_run_result {
     int64_t sweep_launches;
     double  wall_ms;          /* device time of the whole call (hipEvents on the stream) */
     int64_t full_sweeps;      /* steps that evaluated the whole lattice (= steps issued unless incremental) */
+    double  min_margin;       /* selection margin of the batch: min over its steps of the distance of r = u * total from the
+                                 nearer end of the chosen event's interval of the cumulative sum, divided by the total
+                                 (this rank's picks; 1.0 if it made none).  The canonical tree sum and the reference's
+                                 sequential sum (kmc_simulation.py:259,265-274) differ by <= ~1e-13 relative: a margin
+                                 below that means the reference's scan could have stopped at the neighbouring event. */
 } cetkmc_run_result;
 
 /* Mode B -- synchronous super-steps (NOT in the reference; SURVEY.md section 8(f)4, DESIGN.md "Mode B").
@@ -165,6 +170,10 @@ typedef struct cetkmc_counters {
     int64_t alg_bytes_table;    /* rate-table refreshes (k_rate_table)                             */
     int64_t table_updates;      /* rate-table refreshes launched                                   */
     int64_t interface_launches; /* full interface-list evaluations launched                        */
+    double  ms_comm;            /* profile 2, multi-rank handles: device time between the hipEvent pairs around every
+                                   collective of the profiled steps (block-sum / event all-gathers, temperature-halo and
+                                   boundary-layer exchanges); part of ms_reduce / ms_select_apply / ms_thermal above   */
+    int64_t comm_calls;         /* collectives those pairs bracketed                               */
 } cetkmc_counters;
 
 const char* cetkmc_last_error(void);

@@ -330,7 +330,7 @@ def test_transfers_and_errors():
     assert res["status"] == 1 and res["done"] == 0     # kmc_simulation.py:260-262
 
 
-@pytest.mark.parametrize("L,n_slabs,n", [(128, 4, 40), (256, 2, 12)])
+@pytest.mark.parametrize("L,n_slabs,n", [(128, 4, 40), (256, 2, 12), (256, 4, 24)])
 def test_full_size_determinism_and_slab_invariance(L, n_slabs, n):
     """BASELINE-size lattices (config-3 workload: pre-filled k<L/4, moving melt pool, latent heat,
     counter-mode species): run-to-run determinism and slab-count invariance of every per-step
@@ -912,4 +912,54 @@ def test_terminated_batch_leaves_a_consistent_engine(oracle_mod):
     assert rg["done"] == ro["done"] == 20
     for f in ("type", "pos", "target", "atom"):
         assert np.array_equal(rg["events"][f], ro["events"][f]), f
+    e.close()
+
+
+def test_selection_margin_is_reported(oracle_mod):
+    """cetkmc_run_result.min_margin (hard part 3): the smallest distance of a pick r = u * total from the
+    nearer end of the chosen event's interval of the cumulative rate sum, relative to the total.  A u placed 1e-13 (relative)
+    inside an event boundary of the canonical sum is flagged; ordinary uniforms are not.  (The reference scans a sequentially
+    rounded sum, kmc_simulation.py:259,265-274, which differs from the tree sum by ~1e-13 relative: a smaller margin means
+    its pick could be the neighbouring event.)"""
+    import cetkmc
+    L = 16
+    state, theta, phi, T, defects = random_lattice(L, 3, fill=0.2)
+    lat = oracle_mod.Lattice(state, theta, phi, T, defects, impurity_c=0.2)
+    sw = lat.sweep()
+
+    def one_step(u):
+        e = cetkmc.Engine(L, impurity_c=0.2)
+        e.upload(state, theta, phi, T, defects)
+        r = e.run_steps(0, 1, 0.0, np.array([u]), None, np.zeros(4), rng_mode=1, seed=1, thermal_mode=0)
+        e.close()
+        assert r["done"] == 1
+        return r
+    r0 = one_step(0.4321)
+    assert 1e-9 < r0["min_margin"] <= 1.0
+    ev = r0["events"][0]
+    # the chosen event's interval ends `margin_hi` above r: move u to just below that end
+    total = r0["totals"][0]
+    want = lat.select_tree(sw["blocksum"], sw["blockcnt"], sw["rowsum"], sw["rowcnt"], 0.4321 * sw["total"])
+    assert tuple(ev["pos"]) == tuple(want.pos) and ev["type"] == want.type
+    # bisect u upwards until the pick changes: the boundary of the chosen event's interval in the canonical sum
+    lo, hi = 0.4321, 0.4321 + 2.0 * ev["rate"] / total
+    assert one_step(hi)["events"][0].tobytes() != ev.tobytes()
+    for _ in range(60):
+        mid = 0.5 * (lo + hi)
+        if one_step(mid)["events"][0].tobytes() == ev.tobytes():
+            lo = mid
+        else:
+            hi = mid
+    near = one_step(lo)
+    assert near["events"][0].tobytes() == ev.tobytes() and near["min_margin"] < 1e-12
+    # a batch reports the minimum over its steps
+    e = cetkmc.Engine(L, impurity_c=0.2)
+    e.upload(state, theta, phi, T, defects)
+    rs = np.random.RandomState(1)
+    u = rs.random_sample(30)
+    u[0] = lo
+    r = e.run_steps(0, 30, 0.0, u, None, rs.random_sample(70), rng_mode=1, seed=1, thermal_mode=0)
+    assert r["done"] == 30 and r["min_margin"] == near["min_margin"]
+    r = e.run_steps(30, 30, 0.0, rs.random_sample(30), None, rs.random_sample(70), rng_mode=1, seed=1, thermal_mode=0)
+    assert r["min_margin"] > 1e-9                                   # reset per batch
     e.close()

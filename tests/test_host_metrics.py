@@ -70,3 +70,25 @@ def test_neighbors_and_misorientation_helpers():
     z = load("metrics")
     got = np.array([kmc_event_rates.compute_misorientation(*row) for row in z["misor_in"]])
     assert np.max(np.abs(got - z["misor_out"])) < 2e-8
+
+
+def test_dropin_engine_caches_are_bounded():
+    """kmc_event_rates / thermal_solver keep device lattices between calls: least recently used first out, close_engines()."""
+    import kmc_event_rates
+    import thermal_solver
+
+    class Fake:
+        def __init__(self):
+            self.closed = False
+
+        def close(self):
+            self.closed = True
+    for mod in (kmc_event_rates, thermal_solver):
+        c = mod._EngineCache(2)
+        a, b = c.get(8, Fake), c.get(9, Fake)
+        assert c.get(8, Fake) is a
+        d = c.get(10, Fake)
+        assert b.closed and not a.closed and len(c) == 2
+        c.close()
+        assert a.closed and d.closed and len(c) == 0
+        assert isinstance(mod._engines, mod._EngineCache) and callable(mod.close_engines)

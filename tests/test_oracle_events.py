@@ -87,3 +87,17 @@ def test_neighbors_and_misorientation(oracle_mod):
     got = np.array([oracle_mod.misorientation(*row) for row in z["misor_in"]])
     assert np.allclose(got, z["misor_out"], rtol=0, atol=5e-16 * np.pi) or np.max(np.abs(got - z["misor_out"])) < 1e-7
     assert np.max(np.abs(got - z["misor_out"])) < 2e-8   # acos is ill-conditioned at |dot|~1
+
+
+def test_oracle_is_clean_under_address_and_ub_sanitizers():
+    """`make -C oracle asan`: cet_oracle.c + oracle/selftest_main.c under -fsanitize=address,undefined on the CPU (every
+    exported entry point on a 16^3 lattice; SURVEY section 5 "race detection / sanitizers")."""
+    import os
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    r = subprocess.run(["make", "-s", "-C", here, "asan"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "oracle sanitizer self-test ok" in r.stdout
