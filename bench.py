@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--no-mode-b", action="store_true", help="skip the extra Mode B (super-step) run")
     ap.add_argument("--no-phases", action="store_true", help="skip the extra per-phase timing run")
     ap.add_argument("--no-recompute", action="store_true", help="skip the extra run of the recompute sweep variant")
+    ap.add_argument("--no-512", action="store_true",
+                    help="skip the extra 512^3 single-GPU sweep measurement (working set 1.2 GB: no Infinity-Cache residency)")
     ap.add_argument("--transport", choices=["rccl", "host"], default="rccl",
                     help="N > 1: RCCL over xGMI (default) or the host-relay transport (ranks may share one GPU; rehearsal only)")
     ap.add_argument("--set-option", action="append", default=[], metavar="KEY=INT", help="cetkmc_set_option before the run")
@@ -292,10 +294,11 @@ def main():
         r = run(step, a.warmup)
         step += r["done"]
     timed_inputs = prepare(step, a.steps)
-    # short runs (the driver's 20 steps): a hipEvent pair on EVERY sweep launch; long runs: every 8th.  The pair rides on the
+    # very short runs (<= 16 steps): a hipEvent pair on EVERY sweep launch; otherwise every 4th (<= 64 steps: at least 5 timed
+    # launches in the driver's 20-step run) or every 8th.  The pair rides on the
     # launch (hipExtLaunchKernelGGL start / stop events: the dispatch's own timestamps, on the engine's stream), which still
     # costs the timed loop ~4 us per timed launch
-    prof_mode = 1 if a.steps <= 64 else 3
+    prof_mode = 1 if a.steps <= 16 else 3
     eng.set_option("reserve_batch", a.steps)       # batch buffers / hipEvents: hipMalloc and hipEventCreate stay out of the timed region
     inputs_staged = stage(timed_inputs, profile=prof_mode)
     barrier()
@@ -342,6 +345,9 @@ def main():
             phases = {k[3:] + "_us_per_step": 1e3 * c[k] / n_ph for k in ("ms_thermal", "ms_interface", "ms_sweep", "ms_reduce",
                                                                            "ms_select_apply")}
             phases["table_interface_us_per_step"] = phases.pop("interface_us_per_step")
+            if dist is not None:
+                # hipEvent pairs around every collective of the profiled steps (block-sum / event all-gathers, temperature halo)
+                phases.update(comm_us_per_step=1e3 * c["ms_comm"] / n_ph, comm_calls_per_step=c["comm_calls"] / n_ph)
             phases.update(steps=n_ph, device_us_per_step=1e3 * rp["wall_ms"] / n_ph,
                           thermal_updates=c["thermal_updates"], table_updates=c["table_updates"],
                           interface_launches=c["interface_launches"],
@@ -350,7 +356,7 @@ def main():
                                "records); thermal / rate table / interface list averaged over their 1-in-20 cadence")
         return phases
 
-    phases = guarded("phases", do_phases) if (not a.no_phases and (N == 1 or a.extras_multi)) else None
+    phases = guarded("phases", do_phases) if not a.no_phases else None       # at N > 1 this is where comm_us_per_step comes from
 
     # ---- the recompute variant of the sweep kernel (nucleation rates evaluated in every sweep instead of looked up)
     def do_recompute():
@@ -401,31 +407,69 @@ def main():
     inc = guarded("incremental_exact", do_incremental) if (not a.no_incremental and (N == 1 or a.extras_multi)) else None
 
     # ---- Mode B (super-steps over 8^3 boxes; not the reference's trajectory, own CPU comparator): executed events/s
-    def do_mode_b():
+    def do_mode_b(null_events):
         nb_steps, nb_warm = 40, 8
         # untimed warm-up (first launch of the Mode B kernels loads their code objects: ~10 ms once per process)
         rw = eng.run_supersteps(st["step"], nb_warm, 8, DEFECT_FRACTION, seed=SEED, thermal_mode=2,
-                                q_planes=synthetic.laser_planes(L, st["step"], nb_warm))
+                                q_planes=synthetic.laser_planes(L, st["step"], nb_warm), null_events=null_events)
         st["step"] += rw["done"]
         qb = synthetic.laser_planes(L, st["step"], nb_steps)
         barrier()
         t2 = time.perf_counter()
-        rb = eng.run_supersteps(st["step"], nb_steps, 8, DEFECT_FRACTION, seed=SEED, thermal_mode=2, q_planes=qb)
+        rb = eng.run_supersteps(st["step"], nb_steps, 8, DEFECT_FRACTION, seed=SEED, thermal_mode=2, q_planes=qb,
+                                null_events=null_events)
         barrier()
         dtb = allreduce(time.perf_counter() - t2, "MAX")
+        st["step"] += rb["done"]
         n_exec = allreduce(float(rb["n_exec"].sum()), "SUM")          # every rank counts the events of its own boxes
         mode_b = None
         if rb["done"] == nb_steps:
+            # algorithmic bytes of one super-step on this rank: the ordinary rate sweep (9 B per owned voxel) + the box picks,
+            # which read the table entry and class byte of the active octant's voxels (1/8 of the owned voxels) once more;
+            # apply / touched-voxel upkeep are scattered ~0.2 KB-per-voxel gathers (profiles/: measured traffic), not counted
+            alg = B_ALG_SWEEP * n_own_b * (1.0 + 1.0 / 8.0)
+            ach = alg / (dtb / nb_steps) / 1e9
             mode_b = {"executed_events_per_s": n_exec / dtb, "ms_per_superstep": 1e3 * dtb / nb_steps,
                       "events_per_superstep": n_exec / nb_steps, "boxes": (L // 8) ** 3, "supersteps": nb_steps,
-                      "warmup_supersteps": nb_warm,
+                      "warmup_supersteps": nb_warm, "null_events": bool(null_events),
+                      "simulated_time_per_superstep_s": float(np.mean(rb["dt_event"] * rb["n_exec"])) if len(rb["n_exec"]) else None,
+                      "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
+                                   "alg_bytes_per_superstep": alg,
+                                   "alg_bytes_definition": "9 B x owned voxels (rate sweep: class u8 + table f64) + 9 B x owned voxels / 8 "
+                                                           "(box picks re-read the active octant's leaves); this rank",
+                                   "timing": "wall time of the timed super-steps / their number (all launches of a super-step)",
+                                   "kernel_avg_us": mode_b_kernels, "kernel_avg_us_source": mode_b_src,
+                                   "note": "Mode B's super-step is a chain of seven launches of which only the sweep streams; the "
+                                           "fraction is whole-super-step bytes over whole-super-step time, the per-kernel "
+                                           "durations come from the committed rocprofv3 trace of this command"},
                       "note": "cetkmc_run_supersteps box=8 on the lattice left by the runs above: one full rate sweep per "
-                              "super-step, every box executes <= 1 event from its active octant (boxes sharded with the "
-                              "slabs; boundary-layer events exchanged with the neighbour ranks every super-step); "
-                              "bit-identical to oracle orc_run_supersteps (tests/test_gpu_mode_b.py); not part of `value`"}
+                              "super-step, every box picks <= 1 event from its active octant (boxes sharded with the slabs; "
+                              "boundary-layer events exchanged with the neighbour ranks every super-step)" +
+                              ("; null events: a box executes its pick with probability R_box / R_max (every event fires in "
+                               "proportion to its rate, DESIGN.md section 12) -- run_kmc(mode='B') default" if null_events else
+                               "; every non-idle box executes (no null events: boxes with few events are over-sampled)") +
+                              "; bit-identical to oracle orc_run_supersteps (tests/test_gpu_mode_b.py); not part of `value`"}
         return mode_b
 
-    mode_b = guarded("mode_b", do_mode_b) if (not a.no_mode_b and L % 8 == 0 and (L // N) % 8 == 0) else None
+    n_own_b = (eng.i1 - eng.i0) * L * L
+    mode_b_kernels, mode_b_src = None, None
+    try:
+        import re as _re
+        cand_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")),
+                            key=lambda f: int(_re.search(r"r(\d+)", os.path.basename(f)).group(1)), reverse=True)
+        for f in cand_files:
+            km = json.load(open(f)).get("kernels_modes")
+            if km and "k_domain_touch" in km:
+                mode_b_kernels = {k: round(km[k]["avg_us"], 2) for k in ("k_sweep_stream", "k_plane_reduce", "k_select", "k_domain_pick8",
+                                                                          "k_domain_rmax", "k_domain_apply", "k_domain_touch",
+                                                                          "k_super_commit", "k_ifc_relist", "k_interface_part") if k in km}
+                mode_b_src = os.path.relpath(f, ROOT)
+                break
+    except Exception:
+        pass
+    mode_b_ok = not a.no_mode_b and L % 8 == 0 and (L // N) % 8 == 0
+    mode_b = guarded("mode_b", lambda: do_mode_b(False)) if mode_b_ok else None
+    mode_b_null = guarded("mode_b_null_events", lambda: do_mode_b(True)) if mode_b_ok else None
 
     ev_over_ms = guarded("event_overhead", lambda: eng.event_overhead(50))
 
@@ -478,6 +522,36 @@ def main():
             "per_update_work_us_per_step": per_update / 20,
             "note": "the same loop in the committed rocprofv3 kernel trace (kernel durations without the hipEvent records: every "
                     "phase boundary above carries one record, ~2 us); interface / thermal / table kernels run once per 20 steps"}
+    def do_hbm_512():
+        """The same sweep kernel where the Infinity Cache cannot help: config 5's lattice edge (512^3, working set 1.2 GB) on
+        this one GPU.  Lattice by the same fill rule, 12 steps of the exact loop (melt-pool update at step 0), the sweep
+        launches timed by their own start / stop events."""
+        L5 = 512
+        e5 = cetkmc.Engine(L5, impurity_c=IMPURITY_C, device=0)
+        try:
+            f5 = synthetic.planes(L5, 0, L5, seed=SEED)
+            e5.upload_planes(0, L5, *f5)
+            del f5
+            e5.set_prev_state(None)
+            n5 = 12
+            u_pick, u_def, u_np = streams(n5 + 4, SEED)
+            r5 = e5.run_steps(0, 4, DEFECT_FRACTION, u_pick, u_def, u_np, rng_mode=1, seed=SEED, thermal_mode=2,
+                              q_planes=synthetic.laser_planes(L5, 0, 4), use_latent=True)
+            rr = e5.run_steps(4, n5, DEFECT_FRACTION, u_pick[4:], u_def[4:], u_np[r5["np_used"]:], rng_mode=1, seed=SEED, thermal_mode=2,
+                              q_planes=synthetic.laser_planes(L5, 4, n5), use_latent=True, profile=1)
+            ms5 = rr["sweep_ms_total"] / max(rr["sweep_launches"], 1)
+            nv5 = float(L5) ** 3
+            ach5 = B_ALG_SWEEP * nv5 / (ms5 * 1e-3) / 1e9
+            return {"L": L5, "kernel": "k_sweep_stream<table> (full-wave rows)", "avg_launch_ms": ms5, "launches_timed": int(rr["sweep_launches"]),
+                    "alg_bytes_per_launch": B_ALG_SWEEP * nv5, "achieved": ach5, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": ach5 / HBM_PEAK_GBS,
+                    "working_set_bytes": int(B_ALG_SWEEP * nv5), "fits_infinity_cache": False,
+                    "device_ms_per_step": rr["wall_ms"] / n5,
+                    "note": "measured live in this run on the same GPU; committed trace + PMC of the same workload: profiles/r03_512_*"}
+        finally:
+            e5.close()
+
+    hbm_512 = guarded("hbm_512", do_hbm_512) if (N == 1 and L == 256 and not a.no_512 and not config5) else None
+
     workloads = {
         "config3": f"config 3: {L}^3 voxel lattice, one MI355X",
         "config4": f"config 4: the {L}^3 lattice of config 3 split into {N} axis-0 slabs, one rank per MI355X (strong scaling)",
@@ -505,11 +579,21 @@ def main():
         "executed_events_per_s_mode_a": steps_per_s,
         "executed_events_per_s_incremental": inc["steps_per_s"] if inc else None,
         "executed_events_per_s_mode_b": mode_b["executed_events_per_s"] if mode_b else None,
+        "executed_events_per_s_mode_b_null_events": mode_b_null["executed_events_per_s"] if mode_b_null else None,
         "candidate_events_per_s": cand / dt,
         "candidate_events_per_step": cand / a.steps, "voxel_updates_per_s": float(L) ** 3 * steps_per_s,
         "device_ms_per_step": r["wall_ms"] / a.steps,
         "roofline": {"bound": "hbm", "kernel": "k_sweep_stream<table>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     # the sweep's working set (rate table f64 + class u8 of the owned planes) is re-read every step and only
+                     # rewritten by a temperature update: when it fits the 256 MiB Infinity Cache the bytes above are served
+                     # from it, not from DRAM -- `achieved` is then fabric / cache bandwidth against the HBM peak
+                     "working_set_bytes": int(B_ALG_SWEEP * n_own), "infinity_cache_bytes": 256 * 2 ** 20,
+                     "fits_infinity_cache": bool(B_ALG_SWEEP * n_own <= 256 * 2 ** 20),
+                     "memory_level": ("Infinity-Cache resident between temperature updates: achieved is cache / fabric bandwidth, NOT "
+                                      "DRAM; see hbm_512 for the cache-free figure") if B_ALG_SWEEP * n_own <= 256 * 2 ** 20 else
+                                     "HBM (working set exceeds the Infinity Cache)",
+                     "hbm_512": hbm_512,
                      "traffic_measured_in_run": False,
                      "avg_launch_ms": sweep_ms, "launches_timed": int(r["sweep_launches"]),
                      "timing": "hipEvent pairs attached to the sweep launches of the timed region (hipExtLaunchKernelGGL start / "
@@ -547,6 +631,15 @@ def main():
                             "candidate_events_per_s": float(nev[:s1].sum()) / sec1 if s1 else None,
                             "cores": 1, "sample": f"first {s1} steps, scalar port ({sec1:.1f} s)"},
             "host_cores_available": os.cpu_count(), "parity_first_steps": base["parity"],
+            "rng_mode": "counter species draw (cetkmc_run_args.rng_mode = 1) on both sides: the reference's per-candidate NumPy draw "
+                        "(kmc_event_rates.py:65; 65 536 MT draws per step at 256^2) is pinned against the reference at L <= 32 only",
+            # SURVEY 8(d) / BASELINE.md section 2: the reference itself cannot travel to this box; its own speed was measured
+            # once, in the survey container (reference source unmodified, identity-jit stand-in for the missing numba, 1 core)
+            "reference_python": {"provenance": "BASELINE.md section 2: reference source, pure-Python mode (numba absent), 1 of 8 x86 "
+                                               "cores of the survey container, python 3.10 / numpy 2.2 -- NOT measured in this run",
+                                 "sweep_s_16": 0.217, "sweep_s_32": 1.33, "sweep_s_48": 4.95, "us_per_voxel_per_step": 42.0,
+                                 "run_kmc_step_s_30": 1.64, "executed_events_per_s_30": 0.61,
+                                 "sweep_s_256_extrapolated": 700.0, "executed_events_per_s_256_extrapolated": 1.0 / 700.0},
         }
     if config5:
         out["defect_refresh"] = {"every_steps": DEFECT_REFRESH_EVERY, "calls": len(refresh_ms),
@@ -563,7 +656,14 @@ def main():
         out["incremental_exact"] = inc
     if mode_b is not None:
         out["mode_b"] = mode_b
+    if mode_b_null is not None:
+        out["mode_b_null_events"] = mode_b_null
     if dist is not None:
+        box = [None] * N
+        dist.all_gather_object(box, {"rank": rank, "owned_planes": [eng.i0, eng.i1], "sweep_avg_launch_ms": sweep_ms,
+                                     "achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "unit": "GB/s",
+                                     "working_set_bytes": int(B_ALG_SWEEP * n_own)})
+        out["roofline"]["per_rank"] = box
         out["multi_rank_checks"] = {"transport_selftest": comm_check, "ranks_agree_on_event_log": ranks_agree,
                                     "note": "self-test: patterned all-gather + neighbour exchange verified before timing (wall "
                                             "microseconds per call incl. the stream synchronisation); event log: sha256 of the "

@@ -140,6 +140,8 @@ struct Handle {
     int thermal_variant = 1;   // 1 = plane-marching LDS kernel, 0 = one thread per voxel
     int thermal_general = 0;   // 1: k_thermal_march also where k_thermal_tiles applies (A/B, tests)
     int therm_ni = THERM_NI;   // planes per block of the marching kernel
+    int therm_ni16 = THERM16_NI;   // planes per block of k_thermal_tiles16
+    int thermal_tiles16 = 0;   // 1: the 16-row k_thermal_tiles16 where tiles apply (A/B, tests: measured slower); 0: k_thermal_tiles
     int ifc_blocks = 64;       // grid of k_interface (grid-stride over the device-side list length)
     int ifc_block = 256;
     size_t shmem_stream = 0;
@@ -792,7 +794,14 @@ int launch_thermal(Handle* h, double dt, int laser, const double* d_q, int use_l
             const double* Tin = h->slabs[s].Tbuf[h->cur];
             double* Tout = h->slabs[s].Tbuf[nxt];
             uint8_t* prev = h->slabs[s].prev;
-            if (h->L % THERM_KT == 0 && h->L % THERM_TJ == 0 && !h->thermal_general) {      // the tiles cover the lattice exactly
+            if (h->L % THERM_KT == 0 && h->L % THERM16_TJ == 0 && !h->thermal_general && h->thermal_tiles16) {   // 16-row tiles (option), covering the lattice exactly
+                ThermalCfg C16 = C;
+                C16.ni = h->therm_ni16;
+                dim3 g16(h->L / THERM_KT, h->L / THERM16_TJ, (v.nloc + C16.ni - 1) / C16.ni);
+                if (laser && use_latent) hipLaunchKernelGGL((k_thermal_tiles16<true, true>), g16, dim3(512), 0, h->stream, v, Tin, Tout, prev, d_q, C16, ssp);
+                else if (laser) hipLaunchKernelGGL((k_thermal_tiles16<true, false>), g16, dim3(512), 0, h->stream, v, Tin, Tout, prev, d_q, C16, ssp);
+                else hipLaunchKernelGGL((k_thermal_tiles16<false, false>), g16, dim3(512), 0, h->stream, v, Tin, Tout, prev, d_q, C16, ssp);
+            } else if (h->L % THERM_KT == 0 && h->L % THERM_TJ == 0 && !h->thermal_general) {      // the 8-row tiles cover the lattice exactly
                 if (laser && use_latent) hipLaunchKernelGGL((k_thermal_tiles<true, true>), grid, dim3(256), 0, h->stream, v, Tin, Tout, prev, d_q, C, ssp);
                 else if (laser) hipLaunchKernelGGL((k_thermal_tiles<true, false>), grid, dim3(256), 0, h->stream, v, Tin, Tout, prev, d_q, C, ssp);
                 else hipLaunchKernelGGL((k_thermal_tiles<false, false>), grid, dim3(256), 0, h->stream, v, Tin, Tout, prev, d_q, C, ssp);
@@ -1078,6 +1087,11 @@ int cetkmc_set_option(void* handle, const char* key, int64_t value)
         h->therm_ni = (int)value;
         return 0;
     }
+    if (!strcmp(key, "thermal_planes_per_block16")) {
+        if (value < 1 || value > 64) return fail("thermal_planes_per_block16 must be 1..64");
+        h->therm_ni16 = (int)value;
+        return 0;
+    }
     if (!strcmp(key, "thermal_lookahead")) { h->thermal_ahead = value ? 1 : 0; return 0; }
     if (!strcmp(key, "reserve_batch")) {
         // device buffers (uniform streams, per-step logs, one laser source plane per temperature update) and hipEvents of a
@@ -1104,10 +1118,11 @@ int cetkmc_set_option(void* handle, const char* key, int64_t value)
     }
     if (!strcmp(key, "thermal_variant")) {
         // 0: one thread per voxel; 1 (default): plane marching -- k_thermal_tiles where the tiles cover the lattice exactly
-        // (L a multiple of 256), else k_thermal_march; 2: k_thermal_march everywhere
-        if (value < 0 || value > 2) return fail("thermal_variant must be 0 (simple), 1 (marching, default) or 2 (marching, general kernel only)");
+        // (L a multiple of 256), else k_thermal_march; 2: k_thermal_march everywhere; 3: like 1 with the 16-row k_thermal_tiles16
+        if (value < 0 || value > 3) return fail("thermal_variant must be 0 (simple), 1 (marching, default), 2 (marching, general kernel only) or 3 (marching, 16-row tiles)");
         h->thermal_general = value == 2 ? 1 : 0;
-        if (value == 2) value = 1;
+        h->thermal_tiles16 = value == 3 ? 1 : 0;
+        if (value >= 2) value = 1;
         h->thermal_variant = (int)value;
         return 0;
     }
@@ -1434,8 +1449,9 @@ int cetkmc_run_steps(void* handle, const cetkmc_run_args* a, cetkmc_run_result* 
     // profile 1: two events per step around the rate-sweep kernel (bench roofline); profile 2: seven per step
     // (thermal | interface | sweep | reduce(+all-gather) | select+apply boundaries) for cetkmc_get_counters
     const int EPS = a->profile == 2 ? 7 : 2;
-    // profile 3: like 1 but only every 8th step carries the two events (an event record costs ~5 us of stream time)
-    const int64_t pstride = a->profile == 3 ? 8 : 1;
+    // profile 3: like 1 but only every 8th step (every 4th in batches of <= 64 steps) carries the two events (a pair costs
+    // ~4 us of stream time)
+    const int64_t pstride = a->profile == 3 ? (n <= 64 ? 4 : 8) : 1;
     auto sampled = [&](int64_t s) { return a->profile == 1 || (a->profile == 3 && s % pstride == 0); };
     if (a->profile) {
         const int64_t need = a->profile == 2 ? EPS * n : 2 * ((n + pstride - 1) / pstride);     // sampled steps only
@@ -1638,6 +1654,7 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
     }
     if (a->box < 8 || a->box > 16 || (a->box & 1) || h->L % a->box) return fail("box must be even, 8..16, and divide L (or equal L: single domain)");
     const bool ranks = multi_rank(h) && h->nranks > 1;
+    if (ranks && h->nranks > 64) return fail("Mode B supports up to 64 ranks");
     if (ranks && (h->L / h->nranks) % a->box) return fail("across ranks the boxes must be aligned to the slabs: (L / nranks) % box == 0");
     int64_t n_therm = 0;
     if (a->thermal_mode) for (int64_t s = 0; s < n; ++s) if ((a->step0 + s) % 20 == 0) ++n_therm;
@@ -1728,7 +1745,7 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
                                (int)h->slabs.size(), h->L, C, (const StepState*)h->d_ss, (const double*)h->d_ktab, d_picks);
         if (C.null_events) {
             // R_max of the super-step: this rank's largest window total, then (across ranks) the largest of all ranks
-            hipLaunchKernelGGL(k_domain_rmax, dim3(1), dim3(1024), 0, h->stream, (const DomPick*)d_picks, D, (const StepState*)h->d_ss,
+            hipLaunchKernelGGL(k_domain_rmax, dim3((D + 1023) / 1024), dim3(1024), 0, h->stream, (const DomPick*)d_picks, D, (const StepState*)h->d_ss,
                                d_rmax, ranks ? h->rank : 0);
             if (ranks) CHK(comm_allgather(h, d_rmax, sizeof(double)));
         }
@@ -1745,7 +1762,8 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
         }
         hipLaunchKernelGGL(k_domain_touch, dim3(2 * ((n_touch + 15) / 16)), dim3(256), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
                            (int)h->slabs.size(), n_touch, (const cetkmc_event*)d_dom, (const StepState*)h->d_ss, (const double*)h->d_ktab);
-        hipLaunchKernelGGL(k_super_commit, dim3(1), dim3(64), 0, h->stream, h->d_ss, d_cnt, h->d_log_total, h->d_log_nev);
+        hipLaunchKernelGGL(k_super_commit, dim3(1), dim3(64), 0, h->stream, h->d_ss, d_cnt, h->d_log_total, h->d_log_nev,
+                           C.null_events ? d_rmax : (double*)nullptr, std::min(C.nranks, 64));
         h->swept = false;
     }
     if (n > 0) CHK(relist(h));        // leave a complete, address-ordered interface list behind (Mode A reads it)

@@ -1981,6 +1981,149 @@ __global__ __launch_bounds__(256) CETKMC_THERM_ATTR void k_thermal_tiles(SlabVie
     }
 }
 
+// k_thermal_tiles16: the same update with 16-row x 256-column tiles and 512 threads per block (thread: two columns of the
+// rows rbase + 4 q, q = 0..3), marching over C.ni planes (default 16).  Against k_thermal_tiles (8 rows, 4 planes):
+//   * the rim of a plane's tile is 2 rows + 2 columns for 16 rows (13 % extra reads instead of 26 %), and the two planes a
+//     march needs beyond its own are amortised over 16 planes instead of 4 (12.5 % instead of 50 %): T is read ~1.28 x and
+//     written once -- 18.2 B per voxel, 1.14 x the algorithmic 16 B (k_thermal_tiles: 23 B, 1.44 x);
+//   * a plane's own values are requested TWO planes ahead (registers prv | cur | nxt | nx2), its rim one plane ahead: the
+//     stencil of plane i needs plane i+1's values, so with a one-plane distance the loads issued at the top of an iteration
+//     were awaited a few instructions later; now a whole iteration's arithmetic and barriers lie in between.
+// Same loads per voxel, same expression order, same bits (test_thermal_kernel_variants_identical).
+// MEASURED SLOWER than k_thermal_tiles in the real loop (laser + latent heat, 256^3: 84.6 us at 8 planes per block, 105 at 16,
+// against 79.7): the update is bound by latency under low occupancy, not by its re-reads.  Kept as
+// option thermal_variant = 3.
+constexpr int THERM16_TJ = 16, THERM16_NI = 16;
+#ifndef CETKMC_THERM16_ATTR
+#define CETKMC_THERM16_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
+template <bool LASER, bool LATENT>
+__global__ __launch_bounds__(512) CETKMC_THERM16_ATTR void k_thermal_tiles16(SlabView S, const double* __restrict__ Tin, double* __restrict__ Tout,
+                                                         uint8_t* __restrict__ prev_state, const double* __restrict__ q_top,
+                                                         ThermalCfg C, const StepState* __restrict__ ss)
+{
+    constexpr int TJ = THERM16_TJ, KT = THERM_KT, LW = KT + 2;
+    __shared__ double tile[(TJ + 2) * LW];
+    const int L = S.L, pitchT = S.pitchT;
+    const int tid = threadIdx.x;
+    const int kc = blockIdx.x * KT, j0 = blockIdx.y * TJ;
+    const int lp0 = blockIdx.z * C.ni, lp1 = min(lp0 + C.ni, S.nloc);
+    const int col = 2 * (tid & 127), rbase = tid >> 7;          // thread: columns kc+col, kc+col+1 of rows rbase+4q
+    const int k0 = kc + col;
+    const int64_t pstride = (int64_t)L * pitchT;
+    int off[4];                                                 // in-plane offsets of the thread's four column pairs
+#pragma unroll
+    for (int q = 0; q < 4; ++q) off[q] = (j0 + rbase + 4 * q) * pitchT + k0;
+    if (ss && ss->status) {                                     // terminated batch: the field is passed through unchanged
+        for (int lp = lp0; lp < lp1; ++lp)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t c = (int64_t)(lp + 2) * pstride + off[q];
+                *reinterpret_cast<double2*>(Tout + c) = *reinterpret_cast<const double2*>(Tin + c);
+            }
+        return;
+    }
+    const int scrub = C.scrub;
+    auto lplane = [&](int i) { return (i < 0 ? 0 : (i > L - 1 ? L - 1 : i)) - (S.gi0 - 2); };   // clamped global plane -> local
+    // rim cells of a plane, one load per thread: threads 0..255 the row above the tile (j0-1), 256..511 the row below (j0+TJ);
+    // threads < 2 (TJ+2) additionally one cell of the two side columns -- all from clamped coordinates (= edge replication)
+    const int rim_col = tid & 255, rim_low = tid >> 8;
+    const int rim_off = (rim_low ? min(j0 + TJ, L - 1) : max(j0 - 1, 0)) * pitchT + kc + rim_col;
+    const int side_row = tid >> 1, side_right = tid & 1;
+    const bool has_side = tid < 2 * (TJ + 2);
+    const int side_off = min(max(j0 + side_row - 1, 0), L - 1) * pitchT + (side_right ? min(kc + KT, L - 1) : max(kc - 1, 0));
+    double prv[4][2], cur[4][2], nxt[4][2], nx2[4][2];
+    auto load_own = [&](int li, double (&dst)[4][2]) {
+        const double* base = Tin + (int64_t)li * pstride;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double2 v = *reinterpret_cast<const double2*>(base + off[q]);
+            dst[q][0] = scrub_T(v.x, C.T_nan, scrub);
+            dst[q][1] = scrub_T(v.y, C.T_nan, scrub);
+        }
+    };
+    load_own(lplane(S.gi0 + lp0 - 1), prv);
+    load_own(lp0 + 2, cur);
+    load_own(lplane(S.gi0 + lp0 + 1), nxt);
+    double rr, rs = 0.0;
+    {
+        const double* plane = Tin + (int64_t)(lp0 + 2) * pstride;
+        rr = plane[rim_off];
+        if (has_side) rs = plane[side_off];
+    }
+    const double dtm = C.dt > 1e-12 ? C.dt : 1e-12;
+    const double dt_alpha = C.dt * C.alpha;
+#pragma unroll 1
+    for (int lp = lp0; lp < lp1; ++lp) {
+        const int li = lp + 2, i = S.gi0 + lp;
+        // requests of this iteration: plane i+2's own values (used two iterations on), plane i+1's rim (used in the next).
+        // After the block's last planes the (unconditional) requests repeat a plane the block has just read: cache hits
+        load_own(lplane(min(i + 2, S.gi0 + lp1)), nx2);
+        const double* plane_n = Tin + (int64_t)min(li + 1, lp1 + 1) * pstride;
+        const double rr_n = plane_n[rim_off];
+        double rs_n = 0.0;
+        if (has_side) rs_n = plane_n[side_off];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double* row = tile + (rbase + 4 * q + 1) * LW + 1 + col;
+            row[0] = cur[q][0]; row[1] = cur[q][1];
+        }
+        tile[(rim_low ? (TJ + 1) * LW : 0) + 1 + rim_col] = scrub_T(rr, C.T_nan, scrub);
+        if (has_side) tile[side_row * LW + (side_right ? KT + 1 : 0)] = scrub_T(rs, C.T_nan, scrub);
+        __syncthreads();
+        const bool top = LASER && (i == L - 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = rbase + 4 * q, j = j0 + r;
+            unsigned st2 = 0, pv2 = 0;
+            if (LATENT && S.row_chg[(int64_t)li * L + j]) {      // wave-uniform (a wave's rows differ by q only)
+                const int64_t sc = S.sidx(li, j, k0);
+                st2 = *reinterpret_cast<const uint16_t*>(S.state + sc);
+                pv2 = *reinterpret_cast<const uint16_t*>(prev_state + sc);
+                *reinterpret_cast<uint16_t*>(prev_state + sc) = (uint16_t)st2;
+            }
+            const double* cell = tile + (r + 1) * LW + 1 + col;
+            const double jm0 = cell[-LW], jm1 = cell[-LW + 1], jp0 = cell[LW], jp1 = cell[LW + 1];
+            const double km0 = cell[-1], kp1 = cell[2];
+            double out[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const double tc = cur[q][h];
+                const double jm = h ? jm1 : jm0, jp = h ? jp1 : jp0;
+                const double km = h ? cur[q][0] : km0, kp = h ? kp1 : cur[q][1];
+                const double d0 = tc * -2.0 + (prv[q][h] + nxt[q][h]);
+                const double d1 = tc * -2.0 + (jm + jp);
+                const double d2 = tc * -2.0 + (km + kp);
+                const double lap = ((d0 + d1) + d2) * C.inv_dx2;
+                double nt;
+                if (!LASER) {
+                    nt = tc + dt_alpha * lap;
+                } else {
+                    double qterm = 0.0;
+                    if (top) {
+                        const double qv = q_top[(int64_t)j * L + k0 + h];
+                        qterm = (qv != 0.0) ? qv / C.rho_cp : 0.0;
+                    }
+                    double dF = 0.0;
+                    if (LATENT && ((pv2 >> (8 * h)) & 255u) == 0 && ((st2 >> (8 * h)) & 255u) != 0) dF = 1.0 / dtm;
+                    const double dTdt = C.alpha * lap + qterm + C.latent_coef * dF;
+                    nt = tc + C.dt * dTdt;
+                }
+                double v = nt < C.clip_lo ? C.clip_lo : nt;
+                out[h] = v > C.clip_hi ? C.clip_hi : v;
+            }
+            *reinterpret_cast<double2*>(Tout + (int64_t)li * pstride + off[q]) = make_double2(out[0], out[1]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            prv[q][0] = cur[q][0]; prv[q][1] = cur[q][1]; cur[q][0] = nxt[q][0]; cur[q][1] = nxt[q][1];
+            nxt[q][0] = nx2[q][0]; nxt[q][1] = nx2[q][1];
+        }
+        rr = rr_n; rs = rs_n;
+    }
+}
+
 // ---- layout conversion -----------------------------------------------------------------------
 // src: contiguous (nplanes, L, L) covering global planes [i_begin, i_begin+nplanes)
 template <class SRC>

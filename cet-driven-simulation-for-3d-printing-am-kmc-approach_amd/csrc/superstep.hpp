@@ -351,23 +351,25 @@ __global__ __launch_bounds__(64) void k_domain_pick8(KParams P, const SlabView* 
     if (lane == 0 && !status) picks[dl] = pk;
 }
 
-// Null events: R_max of this rank's boxes (one block; picks are L2-resident, written by the pick kernel just before) into
-// rmax[rank]; across ranks the entries are all-gathered and k_domain_apply takes the largest.
+// Null events: R_max of this rank's boxes into rmax[rank] (zero at launch: k_super_commit clears it); across ranks the
+// entries are all-gathered and k_domain_apply takes the largest.  One block per 1024 boxes, the block maxima meet in one
+// 64-bit atomic max (positive doubles order like their bit patterns; a maximum does not depend on the order of arrival).
 __global__ __launch_bounds__(1024) void k_domain_rmax(const DomPick* __restrict__ picks, int D, const StepState* __restrict__ ss,
                                                        double* __restrict__ rmax, int rank)
 {
     __shared__ double wm[16];
     if (ss->status) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int d = blockIdx.x * 1024 + tid;
     double m = 0.0;
-    for (int d = tid; d < D; d += 1024) { const DomPick& p = picks[d]; if (p.type >= 0 && p.R > m) m = p.R; }
+    if (d < D) { const double R = picks[d].R; if (picks[d].type >= 0 && R > m) m = R; }
 #pragma unroll
     for (int l = 0; l < 6; ++l) { const double o = __shfl_xor(m, 1 << l); m = o > m ? o : m; }
     if (lane == 0) wm[w] = m;
     __syncthreads();
     if (tid == 0) {
         for (int q = 1; q < 16; ++q) m = wm[q] > m ? wm[q] : m;
-        rmax[rank] = m;
+        if (m > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(rmax + rank), (unsigned long long)__double_as_longlong(m));
     }
 }
 
@@ -546,10 +548,12 @@ __global__ __launch_bounds__(256) void k_ifc_relist(SlabView S, const StepState*
     }
 }
 
-__global__ __launch_bounds__(64) void k_super_commit(StepState* ss, unsigned long long* counters, double* log_total, int64_t* log_exec)
+__global__ __launch_bounds__(64) void k_super_commit(StepState* ss, unsigned long long* counters, double* log_total, int64_t* log_exec,
+                                                     double* rmax, int nranks)
 {
     if (ss->status) return;
     const int lane = threadIdx.x;
+    if (rmax && lane < nranks) rmax[lane] = 0.0;            // the next super-step's window-total maxima start from zero
     long long ex = 0, nu = 0;
     for (int q = lane; q < SUPER_CNT_SLOTS; q += 64) {
         unsigned long long* slot = counters + (size_t)q * SUPER_CNT_STRIDE;

@@ -103,8 +103,8 @@ typedef struct cetkmc_run_args {
     const double* q_planes;   /* thermal_mode 2: [n_q][L*L] source planes, consumed in order */
     int64_t n_q;
     int32_t use_latent;       /* thermal_mode 2: latent-heat term on/off                */
-    int32_t profile;          /* 1: time every rate-sweep launch with hipEvents; 3: every 8th launch (an event record costs
-                                 ~5 us of stream time); 2: time every phase (cetkmc_get_counters) */
+    int32_t profile;          /* 1: time every rate-sweep launch with hipEvents; 3: every 8th launch, every 4th in batches of <= 64
+                                 steps (an event pair costs ~4 us of stream time); 2: time every phase (cetkmc_get_counters) */
     int32_t incremental;      /* 0: every step evaluates the whole lattice (get_event_rates, kmc_event_rates.py:162);
                                  1: exact incremental mode -- between temperature updates only the rows whose
                                     rates the previous event can have changed are re-evaluated (identical
@@ -217,8 +217,9 @@ int cetkmc_sync(void* handle);
  * whole interface list before every full sweep instead of only after a temperature update; "thermal_lookahead" 1 = the next
  * temperature update of a batch and its rate table are computed ahead on a second stream (single process; same bits;
  * default 0: measured slower); "thermal_variant" 0 = one thread per voxel, 1 = plane marching (default:
- * k_thermal_tiles where 8 x 256 tiles cover the lattice exactly, else k_thermal_march), 2 = k_thermal_march everywhere;
- * "thermal_planes_per_block"; "reserve_batch" n = allocate the
+ * k_thermal_tiles where 8 x 256 tiles cover the lattice exactly, else k_thermal_march), 2 = k_thermal_march everywhere,
+ * 3 = like 1 with the 16-row k_thermal_tiles16 (less traffic, measured slower: DESIGN.md section 13);
+ * "thermal_planes_per_block" (march / 8-row tiles), "thermal_planes_per_block16" (16-row tiles); "reserve_batch" n = allocate the
  * device buffers and hipEvents of a batch of n steps now (a bench keeps hipMalloc / hipEventCreate out of its timed region) */
 int cetkmc_set_option(void* handle, const char* key, int64_t value);
 /* planes [*i0,*i1) owned by this handle (whole lattice unless created with create_rank) */

@@ -25,7 +25,9 @@ def _free_port():
 def _inputs(L, n, seed):
     sys.path.insert(0, HERE)
     from helpers import random_lattice
-    fields = random_lattice(L, seed, fill=0.25)
+    # (at 128^2 top-plane candidates the 5 % melt-hot voxels of the generator make the deposition rates sum to inf, which
+    # ends a run at its first step -- kmc_simulation.py:260-262; the large case keeps every temperature below the melting point)
+    fields = random_lattice(L, seed, fill=0.25, hot_frac=0.0 if L >= 128 else 0.05)
     rs = np.random.RandomState(seed + 1)
     return fields, (rs.random_sample(n), rs.random_sample(n), rs.random_sample(n * (L * L + 2)))
 
@@ -145,7 +147,7 @@ def _worker_b(rank, world, port, L, n, box, thermal_mode, out_dir, null_events=F
 
 @pytest.mark.parametrize("world,L,box,thermal_mode,null_events", [(2, 32, 8, 1, False), (4, 64, 8, 2, False), (2, 64, 16, 2, False),
                                                                   (3, 48, 8, 1, False), (2, 32, 8, 1, True), (3, 48, 8, 2, True),
-                                                                  (4, 128, 8, 1, True)])
+                                                                  (4, 128, 8, 0, True)])
 def test_mode_b_ranks_sharing_one_gpu_match_single_process(world, L, box, thermal_mode, null_events, tmp_path):
     """cetkmc_run_supersteps with one slab per rank (boxes sharded with the slabs, block sums all-gathered, the events
     of the boundary box layers exchanged with the neighbour ranks every super-step) reproduces the single-process

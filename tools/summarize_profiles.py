@@ -70,6 +70,16 @@ if modes:       # second pass: the incremental and Mode B loops (their kernels o
         summary["kernels_modes"][kname(r["Name"])] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
                                                       "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3,
                                                       "pct": float(r["Percentage"])}
+for which in ("fetch", "write"):          # Mode B / incremental kernels: PMC passes of the command that includes them
+    f = one(f"{tag}_modes_pmc_{which}/*/*counter_collection.csv")
+    if not f or "kernels_modes" not in summary:
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        agg[kname(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    for name, v in agg.items():
+        if name in summary["kernels_modes"]:
+            summary["kernels_modes"][name][f"{which}_size_kb_median"] = statistics.median(v)
 for f in (f"{tag}_bench.json", f"{tag}_bench_under_rocprof.json"):
     p = os.path.join(src, f)
     if os.path.exists(p) and os.path.getsize(p):
