@@ -527,16 +527,22 @@ __global__ __launch_bounds__(256) CETKMC_SWEEP_ATTR void k_sweep_stream(StreamAr
     const uint4* cls4 = reinterpret_cast<const uint4*>(A.cls + (int64_t)j0 * pitchC);
     // class slab of local plane lsrc (rows j0-2 .. j0+TJ+1) -> registers -> ring slot lsrc % STREAM_SLOTS.  Unconditional,
     // clamped loads: straight-line code, so the compiler can count what is in flight.
-    uint4 pf[NPF];
+    // (three named registers, not an array: an array captured by the lambdas below is not promoted out of private memory for
+    // NPF > 1 -- the 512^3 sweep then wrote and re-read its prefetched slab through SCRATCH, 256 B per thread and launch:
+    // 256 MiB of writes + as many reads on top of 1.2 GB of algorithmic traffic, profiles/r03_512_*)
+    static_assert(NPF >= 1 && NPF <= 3, "class-slab prefetch registers");
+    uint4 pf0 = make_uint4(0u, 0u, 0u, 0u), pf1 = pf0, pf2 = pf0;
     auto fetch_slab = [&](int lsrc) {
         const uint4* src = cls4 + min(lsrc, A.nloc + 3) * pstride;
-#pragma unroll
-        for (int q = 0; q < NPF; ++q) pf[q] = src[min(tid + 256 * q, nchunk - 1)];
+        pf0 = src[min(tid, nchunk - 1)];
+        if (NPF > 1) pf1 = src[min(tid + 256, nchunk - 1)];
+        if (NPF > 2) pf2 = src[min(tid + 512, nchunk - 1)];
     };
     auto store_slab = [&](int lsrc) {
         uint4* dst = reinterpret_cast<uint4*>(smem + (lsrc % STREAM_SLOTS) * slab);
-#pragma unroll
-        for (int q = 0; q < NPF; ++q) if (tid + 256 * q < nchunk) dst[tid + 256 * q] = pf[q];
+        if (tid < nchunk) dst[tid] = pf0;
+        if (NPF > 1) { if (tid + 256 < nchunk) dst[tid + 256] = pf1; }
+        if (NPF > 2) { if (tid + 512 < nchunk) dst[tid + 512] = pf2; }
     };
     // work items: (plane, row pass); a wave's row of pass rr is j0 + r(rr).  The values of item n+1 and the class slab of
     // the next plane are requested before item n is computed; two value buffers alternate (no register copies).
@@ -568,8 +574,16 @@ __global__ __launch_bounds__(256) CETKMC_SWEEP_ATTR void k_sweep_stream(StreamAr
         // next plane's new slab: requested first, stored at the end of this plane while the value loads are still in flight.
         // After the block's last plane the (unconditional) requests go to what the block has just read -- its last slab, its
         // last plane's values: cache hits, not another block's data dragged across the fabric for nothing
+#ifdef CETKMC_NO_TAIL_PREFETCH
+        const bool more = lp + 1 < lp1;                                 // A/B: no requests beyond the block's own planes
+        if (more) fetch_slab(li + 3);
+#else
         fetch_slab(min(li + 3, lp1 + 3));
+#endif
         if (NP == 1) {
+#ifdef CETKMC_NO_TAIL_PREFETCH
+            if (more)
+#endif
             load_vals<TAB, HW>(A, min(li + 1, lp1 + 1), j0 + row_of(0), lane, 0, nxt);
             const int r = row_of(0);
             auto rowp = [&](int d, int dj) { return (const uint8_t*)smem + so[d + 2] + (r + 2 + dj) * pitchC + KOFFC; };
@@ -582,12 +596,18 @@ __global__ __launch_bounds__(256) CETKMC_SWEEP_ATTR void k_sweep_stream(StreamAr
                 sweep_row<TAB, HW, CH2>(A, rowp, li, lp, j0 + r, top, lane, cur);
             }
             {
+#ifdef CETKMC_NO_TAIL_PREFETCH
+                if (more)
+#endif
                 load_vals<TAB, HW>(A, min(li + 1, lp1 + 1), j0 + row_of(0), lane, 0, cur);
                 const int r = row_of(1);
                 auto rowp = [&](int d, int dj) { return (const uint8_t*)smem + so[d + 2] + (r + 2 + dj) * pitchC + KOFFC; };
                 sweep_row<TAB, HW, CH2>(A, rowp, li, lp, j0 + r, top, lane, nxt);
             }
         }
+#ifdef CETKMC_NO_TAIL_PREFETCH
+        if (more)
+#endif
         store_slab(li + 3);                  // the sixth slot: not among the five this plane's stencil reads
         __syncthreads();
     };
