@@ -699,11 +699,14 @@ int launch_select(Handle* h, const BatchCfg& cfg, double r_direct, int info_only
 int launch_select_apply(Handle* h, const BatchCfg& cfg, int eval_touched, int* dirty, int64_t cur_hint)
 {
     if (!multi_rank(h)) {
-        hipLaunchKernelGGL(k_select_apply, dim3(1), dim3(256), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur],
-                           (int)h->slabs.size(), h->L, h->PB, (const BlockEnt*)h->d_blocks, h->d_ss, cfg,
-                           (const double*)h->d_u_pick, (const double*)h->d_ktab, h->d_events_all + h->my_first,
-                           h->sweep_variant >= 1 ? 1 : 0, (const double*)h->d_u_defect, (const double*)h->d_u_np,
-                           h->d_log_total, h->d_log_event, h->d_log_nev, eval_touched, dirty, (long long)cur_hint);
+#define CETKMC_LAUNCH_SELAPPLY(IFC)                                                                                              \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_select_apply<IFC>), dim3(1), dim3(256), 0, h->stream, h->kp, (const SlabView*)h->d_views[h->cur], \
+                       (int)h->slabs.size(), h->L, h->PB, (const BlockEnt*)h->d_blocks, h->d_ss, cfg,                               \
+                       (const double*)h->d_u_pick, (const double*)h->d_ktab, h->d_events_all + h->my_first,                         \
+                       IFC ? 1 : 0, (const double*)h->d_u_defect, (const double*)h->d_u_np,                                         \
+                       h->d_log_total, h->d_log_event, h->d_log_nev, eval_touched, dirty, (long long)cur_hint)
+        if (h->sweep_variant >= 1) CETKMC_LAUNCH_SELAPPLY(true); else CETKMC_LAUNCH_SELAPPLY(false);
+#undef CETKMC_LAUNCH_SELAPPLY
         HIPCHK(hipGetLastError());
         return 0;
     }

@@ -847,6 +847,7 @@ __device__ __forceinline__ TreeSel tree_select(const double (&lf)[8], unsigned f
 // k_select: single block.  (1) total + termination checks, (2) block descent, (3) row descent
 // in the owning slab, (4) voxel descent (leaves looked up in the rate table), (5) slot scan.
 // cur_hint >= 0: the batch step index as the host knows it (== ss->cur while status == 0): saves a dependent load.
+template <bool IFC>
 __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __restrict__ slabs, int nslabs, int L,
                                             int PB, const BlockEnt* __restrict__ blocks, StepState* ss,
                                             const BatchCfg& cfg, const double* __restrict__ u_pick, double r_direct,
@@ -1003,7 +1004,7 @@ __device__ __forceinline__ void select_body(const KParams& P, const SlabView* __
             int maybe_ifc = 1;      // 0: certainly no interface voxel (its EMPTY category can only hold a nucleation)
             if (k < L) {
                 const int64_t t = S.tidx(li, j, k);
-                if (ifc_ready) {
+                if (IFC) {
                     // table entry and class byte (one round trip): the byte says whether the voxel is empty (bit 0) and how
                     // many events a LISTED voxel owns (bits 7:2, ifc_store(); zero for every voxel that is not listed --
                     // and a listed voxel without events holds a zero table entry, so it reads like an unlisted one)
@@ -1103,7 +1104,9 @@ __global__ __launch_bounds__(256) void k_select(KParams P, const SlabView* __res
                                                 BatchCfg cfg, const double* __restrict__ u_pick, double r_direct,
                                                 const double* __restrict__ ktab_g, cetkmc_event* my_event, int info_only, int ifc_ready)
 {
-    select_body(P, slabs, nslabs, L, PB, blocks, ss, cfg, u_pick, r_direct, ktab_g, my_event, info_only, ifc_ready);
+    // (two instantiations: the table path carries none of the per-voxel evaluation code of the simple-kernel path)
+    if (ifc_ready) select_body<true>(P, slabs, nslabs, L, PB, blocks, ss, cfg, u_pick, r_direct, ktab_g, my_event, info_only, 1);
+    else select_body<false>(P, slabs, nslabs, L, PB, blocks, ss, cfg, u_pick, r_direct, ktab_g, my_event, info_only, 0);
 }
 
 // ---- interface voxels --------------------------------------------------------------------
@@ -1586,6 +1589,7 @@ __global__ __launch_bounds__(64) void k_apply_batch(KParams P, const SlabView* _
 }
 // Single-process batched loop: selection and application in one launch (the event record never leaves the block's
 // view of memory; threads >= 64 only take part in the barriers of the apply part).
+template <bool IFC>
 __global__ __launch_bounds__(256) void k_select_apply(KParams P, const SlabView* __restrict__ slabs, int nslabs, int L,
                                                       int PB, const BlockEnt* __restrict__ blocks, StepState* ss,
                                                       BatchCfg cfg, const double* __restrict__ u_pick,
@@ -1599,7 +1603,7 @@ __global__ __launch_bounds__(256) void k_select_apply(KParams P, const SlabView*
     (void)my_event;
     if (threadIdx.x == 0) sh_sel.type = -1;
     __syncthreads();
-    select_body(P, slabs, nslabs, L, PB, blocks, ss, cfg, u_pick, 0.0, ktab_g, &sh_sel, 0, ifc_ready, cur_hint, &sh_carry, u_defect, u_np);
+    select_body<IFC>(P, slabs, nslabs, L, PB, blocks, ss, cfg, u_pick, 0.0, ktab_g, &sh_sel, 0, ifc_ready, cur_hint, &sh_carry, u_defect, u_np);
     __syncthreads();
     apply_batch_body(P, slabs, nslabs, L, &sh_sel, 1, ss, cfg, u_defect, u_np, log_total, log_event, log_nev, ktab_g,
                      eval_touched, dirty, &sh_carry);

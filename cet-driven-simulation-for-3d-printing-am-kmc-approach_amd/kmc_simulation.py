@@ -101,7 +101,7 @@ def _advance_to(engine, first, last, L, defect_fraction, rng_mode=0, seed=0, inc
     return step - first, terminated, last_total, dts
 
 
-def save_checkpoint(path, fields, defects_mask, next_step, total_time, nucleation_count, metrics_data, cet_detected):
+def save_checkpoint(path, fields, defects_mask, next_step, total_time, nucleation_count, metrics_data, cet_detected, extra=None):
     """Everything needed to continue a run bit-identically: the five lattice fields, the defect mask,
     the loop counters, the metrics rows so far and the state of BOTH host generators (CPython
     ``random`` and NumPy's legacy global stream).  The reference has no resume."""
@@ -115,7 +115,8 @@ def save_checkpoint(path, fields, defects_mask, next_step, total_time, nucleatio
         nucleation_count=nucleation_count, cet_detected=bool(cet_detected),
         py_version=py[0], py_mt=np.array(py[1], dtype=np.uint64), py_gauss=np.array([np.nan if py[2] is None else py[2]]),
         np_mt=npst[1], np_pos=npst[2], np_has_gauss=npst[3], np_cached=npst[4],
-        metrics_json=np.array(json.dumps(metrics_data, default=lambda o: o.item() if hasattr(o, "item") else str(o))))
+        metrics_json=np.array(json.dumps(metrics_data, default=lambda o: o.item() if hasattr(o, "item") else str(o))),
+        extra_json=np.array(json.dumps(extra or {})))          # mode "B": super-step index, temperature updates applied, seed, box
     os.replace(tmp, path)
 
 
@@ -129,7 +130,8 @@ def load_checkpoint(path):
     return dict(state=z["state"].astype(np.int64), theta=z["theta"], phi=z["phi"], T=z["T"],
                 defects=z["defects"].astype(np.int64), next_step=int(z["next_step"]), total_time=float(z["total_time"]),
                 nucleation_count=int(z["nucleation_count"]), cet_detected=bool(z["cet_detected"]),
-                metrics_data=json.loads(str(z["metrics_json"])))
+                metrics_data=json.loads(str(z["metrics_json"])),
+                extra=json.loads(str(z["extra_json"])) if "extra_json" in z.files else {})
 
 
 def run_kmc(
@@ -158,8 +160,9 @@ def run_kmc(
     becomes a defect.
 
     Extensions (keyword-only, not in the reference): ``checkpoint_every=k`` writes
-    ``outputs/<prefix>/checkpoint.npz`` every k steps; ``resume_from=path`` continues such a run --
-    the continued run is bit-identical to an uninterrupted one (lattice, time, CSV, RNG streams);
+    ``outputs/<prefix>/checkpoint.npz`` every k steps (mode "B": after the super-step that reaches each multiple of k
+    executed events); ``resume_from=path`` continues such a run --
+    the continued run is bit-identical to an uninterrupted one (lattice, time, CSV, RNG streams), in both modes;
     ``incremental=False`` re-evaluates the whole lattice on every step like get_event_rates does (the
     default re-evaluates only the rows an event made stale between temperature updates -- same results);
     ``nu_dep`` overrides constants.NU_DEP (deposition attempt frequency = growth velocity V of the G-V sweep
@@ -185,8 +188,6 @@ def run_kmc(
         raise ValueError("mode must be 'A' (exact, one event per sweep) or 'B' (super-steps)")
     if thermal_cadence not in ("events", "supersteps"):
         raise ValueError("thermal_cadence must be 'events' or 'supersteps'")
-    if mode == "B" and (checkpoint_every or resume_from):
-        raise ValueError("checkpoint / resume is implemented for mode 'A' only")
     run_seed = RANDOM_SEED if seed is None else int(seed)
     metrics_every = int(metrics_every)
 
@@ -316,11 +317,26 @@ def run_kmc(
         nbx = L // box if (box and L % box == 0) else 1
         d_max = 1 if box == L else nbx ** 3                       # events per super-step at most
         executed, g, thermal_done = 0, 0, 0
+        mb_cfg = dict(mode="B", box=int(box), seed=run_seed, null_events=bool(null_events), thermal_cadence=thermal_cadence,
+                      thermal_updates=bool(thermal_updates))
+        if ckpt:
+            ex = ckpt["extra"]
+            if {k: ex.get(k) for k in mb_cfg} != mb_cfg:
+                raise ValueError(f"checkpoint was written by a run with {ex}, this call asks for {mb_cfg}")
+            executed, g, thermal_done = next_step, int(ex["superstep"]), int(ex["thermal_done"])
         by_events = thermal_cadence == "events" and thermal_updates
+
+        def checkpoint_b():
+            save_checkpoint(os.path.join(output_dir, "checkpoint.npz"), engine.download(),
+                            engine.download(state=False, theta=False, phi=False, T=False, defects=True)["defects"],
+                            executed, total_time, nuc_offset + engine.nucleation_count(), metrics_data, cet_detected,
+                            extra=dict(mb_cfg, superstep=g, thermal_done=thermal_done))
         while executed < n_steps:
-            # super-steps until (at the earliest) the next metrics boundary / the end: a super-step executes <= d_max events
-            # (a row is due once executed - 1 reaches the next multiple of metrics_every)
+            # super-steps until (at the earliest) the next metrics / checkpoint boundary or the end: a super-step executes
+            # <= d_max events (a row is due once executed - 1 reaches the next multiple of metrics_every)
             boundary = min(((executed - 1) // metrics_every + 1) * metrics_every + 1, n_steps)
+            if checkpoint_every > 0:
+                boundary = min(boundary, (executed // checkpoint_every + 1) * checkpoint_every)
             nb = max(1, (boundary - executed) // d_max)
             if by_events:
                 # kmc_simulation.py:248-250: event index e is preceded by e // 20 + 1 temperature updates; the super-step's
@@ -344,6 +360,8 @@ def run_kmc(
             crossed = (executed - 1) // metrics_every > (before - 1) // metrics_every
             if crossed or executed >= n_steps:
                 metrics_row(step, crossed)
+            if checkpoint_every > 0 and executed // checkpoint_every > before // checkpoint_every:
+                checkpoint_b()          # after the row of this super-step: a resumed run continues with the next super-step
         next_step = executed
 
     if metrics_data:

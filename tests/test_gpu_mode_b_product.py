@@ -92,9 +92,38 @@ def test_run_kmc_mode_b_supersteps_cadence_and_argument_errors(tmp_path, monkeyp
     assert np.all(np.diff(df["Step"].values) > 0) and np.all(np.diff(df["Time"].values) > 0)
     assert abs(total_time - (df["Step"].iloc[-1] + 1) * 1e-12) <= 1e-9 * total_time       # the 1e-12 floor binds
     assert df["W_Count"].iloc[-1] + df["Re_Count"].iloc[-1] + df["C_Count"].iloc[-1] > 2000
-    for bad in (dict(box=6), dict(box=20), dict(mode="C"), dict(thermal_cadence="x"), dict(checkpoint_every=10)):
+    for bad in (dict(box=6), dict(box=20), dict(mode="C"), dict(thermal_cadence="x")):
         with pytest.raises(ValueError):
             kmc_simulation.run_kmc(L=32, n_steps=10, output_prefix="mb_bad", **{"mode": "B", **bad})
+
+
+@pytest.mark.parametrize("cadence", ["events", "supersteps"])
+def test_run_kmc_mode_b_checkpoint_resume_is_bit_identical(cadence, tmp_path, monkeypatch):
+    """checkpoint_every / resume_from in mode "B": a run continued from its checkpoint ends with the same lattice, time and
+    CSV as the uninterrupted run (the checkpoint carries the super-step index, the temperature updates applied and both host
+    generators; Mode B's uniforms are functions of (seed, super-step, box))."""
+    import shutil
+
+    import kmc_simulation
+    monkeypatch.chdir(tmp_path)
+    kw = dict(L=24, n_steps=1500, defect_fraction=0.01, n_seeds=6, impurity_c=0.2, mode="B", box=8, seed=5, metrics_every=300,
+              thermal_cadence=cadence)
+    full = kmc_simulation.run_kmc(output_prefix="cb_full", **kw)
+    # (the interrupted run goes on to 1000 events: its last checkpoint -- after the super-step that reached 800 -- holds the
+    # rows of the crossings 0 / 300 / 600 only, not the final row of that shorter run)
+    kmc_simulation.run_kmc(output_prefix="cb_part", **{**kw, "n_steps": 1000}, checkpoint_every=400)
+    ck = "outputs/cb_part/checkpoint.npz"
+    z = np.load(ck)
+    assert 800 <= int(z["next_step"]) < 900
+    os.makedirs("outputs/cb_res", exist_ok=True)
+    shutil.copy(ck, "outputs/cb_res/start.npz")
+    res = kmc_simulation.run_kmc(output_prefix="cb_res", **kw, resume_from="outputs/cb_res/start.npz")
+    for a, b in zip(full, res):
+        assert np.array_equal(a, b)
+    fa, fb = pd.read_csv("outputs/cb_full/metrics.csv"), pd.read_csv("outputs/cb_res/metrics.csv")
+    assert fa.equals(fb)
+    with pytest.raises(ValueError, match="checkpoint was written"):
+        kmc_simulation.run_kmc(output_prefix="cb_bad", **{**kw, "box": 12}, resume_from="outputs/cb_res/start.npz")
 
 
 def test_gv_sweep_in_mode_b(tmp_path, monkeypatch):
