@@ -132,7 +132,8 @@ struct Handle {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
     bool swept = false;
-    int sweep_variant = 1;     // 0 simple, 1 streaming + rate table (default), 2 streaming, nucleation rates recomputed per sweep
+    int sweep_variant = 1;     // 0 simple, 1 streaming + rate table with the LDS census (default), 2 streaming, nucleation rates
+                               // recomputed per sweep, 3 census-free table sweep (same bits, measured no faster: DESIGN.md section 13)
     bool table_fresh = false;  // vval / dep_val match the current T and parameters (k_rate_table)
     bool ifc_fresh = false;    // vval / event count (class byte) of every listed voxel match the current lattice, T, defects and parameters
     int ifc_every_step = 0;    // 1: k_interface before every full sweep (round-1 behaviour, A/B); 0: only when stale --
@@ -605,7 +606,7 @@ int launch_dirty_rows(Handle* h, hipEvent_t ev_a, hipEvent_t ev_b)
         const int* dl = h->d_dirty;
         int* pc = h->d_dirty + 1 + DIRTY_MAX;
         const StepState* ss = h->d_ss;
-        const bool tab = h->sweep_variant == 1, hw = h->Pk <= 256, ch2 = h->Pk > 512;
+        const bool tab = h->sweep_variant == 1 || h->sweep_variant == 3, hw = h->Pk <= 256, ch2 = h->Pk > 512;
 #define CETKMC_LAUNCH_ROWS(TAB, HW, CH2) \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows_eval<TAB, HW, CH2>), dim3(24), dim3(256), 0, h->stream, sa, dl, ss, h->d_blocks, pc)
         if (hw) { if (tab) CETKMC_LAUNCH_ROWS(true, true, false); else CETKMC_LAUNCH_ROWS(false, true, false); }
@@ -649,7 +650,23 @@ int launch_sweep(Handle* h, bool batch, hipEvent_t ev_a = nullptr, hipEvent_t ev
     if (ev_a && !ext) HIPCHK(hipEventRecord(ev_a, h->stream));
     for (size_t s = 0; s < h->slabs.size(); ++s) {
         SlabView v = view_of(h, (int)s);
-        if (h->sweep_variant >= 1) {
+        if (h->sweep_variant == 3) {
+            // census-free table sweep: class bytes + rate table streamed once, no LDS
+            const StreamArgs sa = stream_args(h, v);
+            const bool hw = h->Pk <= 256, ch2 = h->Pk > 512;
+            const int ipp = hw ? (h->L + 1) / 2 : h->L;
+            const int64_t n_items = (int64_t)ipp * v.nloc;
+            const dim3 g((unsigned)((n_items + 4 * TABLE_IPW - 1) / (4 * TABLE_IPW)));
+#define CETKMC_LAUNCH_TABLE(HW, CH2)                                                                                             \
+    do {                                                                                                                         \
+        if (ext) hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_table<HW, CH2>), g, dim3(256), 0, h->stream, ev_a, ev_b, 0, sa, ss); \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_table<HW, CH2>), g, dim3(256), 0, h->stream, sa, ss);                     \
+    } while (0)
+            if (hw) CETKMC_LAUNCH_TABLE(true, false);
+            else if (!ch2) CETKMC_LAUNCH_TABLE(false, false);
+            else CETKMC_LAUNCH_TABLE(false, true);
+#undef CETKMC_LAUNCH_TABLE
+        } else if (h->sweep_variant >= 1) {
             const StreamArgs sa = stream_args(h, v);
             const dim3 g(sa.group_count * njt);
             const bool tab = h->sweep_variant == 1, hw = h->Pk <= 256;
@@ -1079,7 +1096,7 @@ int cetkmc_set_option(void* handle, const char* key, int64_t value)
     Handle* h = (Handle*)handle;
     if (!h || !key) return fail("null argument");
     if (!strcmp(key, "sweep_variant")) {
-        if (value < 0 || value > 2) return fail("sweep_variant must be 0 (simple), 1 (streaming + rate table, default) or 2 (streaming, recompute)");
+        if (value < 0 || value > 3) return fail("sweep_variant must be 0 (simple), 1 (streaming + rate table, default), 2 (streaming, recompute) or 3 (census-free table sweep)");
         h->sweep_variant = (int)value;
         h->swept = false; h->table_fresh = false; h->ifc_fresh = false;
         return 0;

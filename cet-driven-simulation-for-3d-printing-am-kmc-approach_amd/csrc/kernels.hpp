@@ -335,9 +335,18 @@ __device__ __forceinline__ void load_vals(const StreamArgs& A, int li, int jrow,
     // whatever they load
     const int k0 = min((m << 9) + 8 * (HW ? (lane & 31) : lane), A.pitchT - 8);
     const int jr = min(jrow, A.L - 1);
+#ifdef CETKMC_COALESCED_TIMING
+    // TIMING ONLY (results wrong): every load instruction reads whole lines -- lane l takes 16 B at 16 l + (HW ? 512 : 1024) q
+    (void)k0;
+    const double2* src = reinterpret_cast<const double2*>((TAB ? A.vval : A.T) + ((int64_t)li * A.L + jr) * A.pitchT + (m << 9));
+    const int nl = HW ? 32 : 64, sl_ = HW ? (lane & 31) : lane;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const double2 t = src[min(q * nl + sl_, A.pitchT / 2 - 1)]; v[2 * q] = t.x; v[2 * q + 1] = t.y; }
+#else
     const double2* src = reinterpret_cast<const double2*>((TAB ? A.vval : A.T) + ((int64_t)li * A.L + jr) * A.pitchT + k0);
 #pragma unroll
     for (int q = 0; q < 4; ++q) { const double2 t = src[q]; v[2 * q] = t.x; v[2 * q + 1] = t.y; }
+#endif
 }
 
 // One lattice row per wave (HW: per half-wave; `jrow` is then the lane's own row) of plane li: census + rates +
@@ -623,6 +632,210 @@ __global__ __launch_bounds__(256) CETKMC_SWEEP_ATTR void k_sweep_stream(StreamAr
     }
 }
 
+// ----------------------------------------------------------------------------------------
+// k_sweep_table (variant 3): the rate sweep WITHOUT a neighbour census.  What the census of k_sweep_stream decides --
+// which atoms own diffusion events, which empty voxels are interface voxels with more than one event -- is already
+// written in every voxel's OWN class byte: bits 7:2 hold the event count of a listed voxel (ifc_store(), kept current by
+// k_interface / ifc_touch / k_domain_touch), and every interface voxel is listed.  So a row reduces from two streams
+// alone, the class bytes (1 B per voxel) and the rate table (8 B per voxel), each read exactly once:
+//   EMPTY sum  = sum over empty voxels (class bit 0) of their table entry; its count = non-zero entries (+ count - 1 of a
+//                listed empty voxel with a count);  DIFF sum = sum over atoms with a non-zero count of their entry;
+//   DEP (plane L-1) as before from dep_val.
+// No LDS ring, no halo planes or rows, no barriers: 9 B per voxel of traffic for 9 B algorithmic.  The sums, counts and
+// the summation tree are those of sweep_row() to the bit (an atom with a non-zero count is an atom with an empty neighbour
+// whose diffusion rates were kept; a listed empty voxel that lost its W/Re/C neighbours holds a count of 0 or 1).
+// A lane handles 8 consecutive voxels; HW: rows of <= 256 voxels occupy half a wave, a wave item is a pair of rows.  A wave
+// walks IPW items 4 apart (the block's four waves read 4 consecutive items at a time), values and class bytes of the next
+// item requested before the current one is reduced.
+// MEASURED: bit-identical, but not faster than k_sweep_stream -- 32.3 vs 31.3 us (sweep + reduce) at 256^3,
+// 229 vs 222 at 512^3; requesting two items ahead or fully coalesced loads make it slower.  The sweep is bound by the memory
+// system (5.6 TB/s of HBM traffic at 512^3), not by the census arithmetic.  Kept as an option and as the row kernel of the
+// incremental mode (k_rows_eval), where it saves the five-plane gather of class rows.
+// ----------------------------------------------------------------------------------------
+__device__ __forceinline__ uint2 load_cls8(const StreamArgs& A, int li, int jrow, int sl, int m)
+{
+    const int k0 = min((m << 9) + 8 * sl, A.pitchT - 8);
+    const int jr = min(jrow, A.L - 1);
+    return *reinterpret_cast<const uint2*>(A.cls + ((int64_t)li * A.RJ + (jr + 2)) * A.pitchC + KOFFC + k0);
+}
+template <bool HW, bool CH2>
+__device__ __forceinline__ void table_row(const StreamArgs& A, int li, int lp, int jrow, bool top, int lane, const double (&v0)[8],
+                                          uint2 own0)
+{
+    static_assert(!(HW && CH2), "half-wave rows have one chunk");
+    const int L = A.L;
+    const int sl = HW ? (lane & 31) : lane;
+    constexpr int nch = CH2 ? 2 : 1;                         // chunks of 512 voxels
+    double r0 = 0.0, r1 = 0.0, r2 = 0.0;
+    int nE_a = 0, nE_b = 0, nD_a = 0, nD_b = 0;
+    int cI = 0;
+    bool any_ifc = false;
+#pragma unroll
+    for (int m = 0; m < nch; ++m) {
+        const int k0 = (m << 9) + 8 * sl;
+        const bool active = jrow < L && k0 < L;
+        double v[8], ev[8];
+        uint2 own = own0;
+        if (m == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = v0[q];
+        } else {
+            load_vals<true, HW>(A, li, jrow, lane, m, v);
+            own = load_cls8(A, li, jrow, sl, m);
+        }
+        if (!active) own = make_uint2(0u, 0u);              // (clamped addresses: whatever such a lane loaded is masked)
+        // bit 0 of every byte: E own voxel empty, Aat own voxel a W/Re/C atom; c6 the count field
+        const uint2 E = make_uint2(own.x & 0x01010101u, own.y & 0x01010101u);
+        const uint2 Aat = make_uint2((own.x >> 1) & 0x01010101u, (own.y >> 1) & 0x01010101u);
+        const uint2 c6 = make_uint2((own.x >> 2) & 0x3F3F3F3Fu, (own.y >> 2) & 0x3F3F3F3Fu);
+#pragma unroll
+        for (int h = 0; h < 8; ++h) ev[h] = mask_f64(v[h], h < 4 ? E.x : E.y, 8 * (h & 3));
+        const uint2 cE = make_uint2(c6.x & (E.x * 255u), c6.y & (E.y * 255u));
+        const uint2 cA = make_uint2(c6.x & (Aat.x * 255u), c6.y & (Aat.y * 255u));
+        const bool diff_here = __any((cA.x | cA.y) != 0u);
+        double dv[8];
+#pragma unroll
+        for (int h = 0; h < 8; ++h) dv[h] = 0.0;
+        if (__any((cE.x | cE.y | cA.x | cA.y) != 0u)) {
+            any_ifc = true;
+            // a listed empty voxel with events is counted once by the ballots below (its sum is non-zero): add count - 1
+            const unsigned nz = __popc(((cE.x + 0x3F3F3F3Fu) >> 6) & 0x01010101u) + __popc(((cE.y + 0x3F3F3F3Fu) >> 6) & 0x01010101u);
+            const unsigned nE = __builtin_amdgcn_sad_u8(cE.x, 0u, __builtin_amdgcn_sad_u8(cE.y, 0u, 0u)) - nz;
+            const unsigned nA = __builtin_amdgcn_sad_u8(cA.x, 0u, __builtin_amdgcn_sad_u8(cA.y, 0u, 0u));
+            cI += (int)(nE | (nA << 16));
+        }
+        if (diff_here) {
+            const uint2 hasA = make_uint2(((cA.x + 0x3F3F3F3Fu) >> 6) & 0x01010101u, ((cA.y + 0x3F3F3F3Fu) >> 6) & 0x01010101u);
+#pragma unroll
+            for (int h = 0; h < 8; ++h) dv[h] = mask_f64(v[h], h < 4 ? hasA.x : hasA.y, 8 * (h & 3));
+        }
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            const unsigned long long bm = __ballot(ev[h] != 0.0);
+            if (HW) { nE_a += __popc((unsigned)bm); nE_b += __popc((unsigned)(bm >> 32)); }
+            else nE_a += __popcll(bm);
+        }
+        double s2 = wave_tree_sum_h<HW>(tree8(ev));
+        r2 = (m == 0) ? s2 : r2 + s2;
+        double s1 = 0.0;                                         // a chunk without diffusing atoms contributes +0.0
+        if (diff_here) s1 = wave_tree_sum_h<HW>(tree8(dv));
+        r1 = (m == 0) ? s1 : r1 + s1;
+        if (top) {          // nu_dep * exp(-(T_melt - T')/(kT T')) of plane L-1 by temperature (k_rate_table): kept iff finite
+            double dp[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dp[q] = 0.0;
+            if (active) {
+                const double2* src = reinterpret_cast<const double2*>(A.dep_val + (int64_t)jrow * A.pitchT + k0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const double2 t = src[q]; dp[2 * q] = t.x; dp[2 * q + 1] = t.y; }
+            }
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                const bool keep = (((h < 4 ? E.x : E.y) >> (8 * (h & 3))) & 1u) && finite_d(dp[h]);
+                dp[h] = keep ? dp[h] : 0.0;
+                const unsigned long long bm = __ballot(keep);
+                if (HW) { nD_a += __popc((unsigned)bm); nD_b += __popc((unsigned)(bm >> 32)); }
+                else nD_a += __popcll(bm);
+            }
+            const double s0 = wave_tree_sum_h<HW>(tree8(dp));
+            r0 = (m == 0) ? s0 : r0 + s0;
+        }
+    }
+    int n2 = HW ? ((lane & 32) ? nE_b : nE_a) : nE_a;
+    const int n0 = HW ? ((lane & 32) ? nD_b : nD_a) : nD_a;
+    int n1 = 0;
+    if (any_ifc) {
+        const int packed = wave_sum_i_h<HW>(cI);
+        n2 += packed & 0xFFFF;
+        n1 = packed >> 16;
+    }
+    if (sl == 0 && jrow < L) {
+        const int64_t o = (int64_t)lp * 3 * L + jrow;
+        A.rowsum[o] = r0; A.rowsum[o + L] = r1; A.rowsum[o + 2 * (int64_t)L] = r2;
+        A.rowcnt[o] = n0; A.rowcnt[o + L] = n1; A.rowcnt[o + 2 * (int64_t)L] = n2;
+    }
+}
+
+#ifndef CETKMC_TABLE_IPW
+#define CETKMC_TABLE_IPW 8
+#endif
+constexpr int TABLE_IPW = CETKMC_TABLE_IPW;       // items per wave
+template <bool HW, bool CH2>
+__global__ __launch_bounds__(256) CETKMC_SWEEP_ATTR void k_sweep_table(StreamArgs A, const StepState* __restrict__ ss)
+{
+    if (ss && ss->status) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int L = A.L;
+    const int ipp = HW ? (L + 1) >> 1 : L;                       // items per plane (HW: pairs of rows)
+    const int n_items = ipp * A.nloc;
+    int b = blockIdx.x;
+    if ((gridDim.x & 7) == 0) b = (b & 7) * (int)(gridDim.x >> 3) + (b >> 3);      // contiguous item ranges per XCD
+    int item = b * 4 * TABLE_IPW + w;
+    if (item >= n_items) return;
+    int lp = item / ipp, jp = item - lp * ipp;
+    const int sl = HW ? (lane & 31) : lane;
+    auto jrow_of = [&](int jpair) { return HW ? 2 * jpair + (lane >> 5) : jpair; };
+#ifdef CETKMC_TABLE_DEPTH2
+    // A/B: requests TWO items ahead (three rotating buffers)
+    double va[8], vb[8], vc[8];
+    uint2 ca, cb, cc;
+    auto advance = [&](int& lpx, int& jpx) { jpx += 4; while (jpx >= ipp) { jpx -= ipp; ++lpx; } };
+    int lp1 = lp, jp1 = jp;
+    advance(lp1, jp1);
+    const bool has1 = item + 4 < n_items;
+    load_vals<true, HW>(A, lp + 2, jrow_of(jp), lane, 0, va);
+    ca = load_cls8(A, lp + 2, jrow_of(jp), sl, 0);
+    load_vals<true, HW>(A, (has1 ? lp1 : lp) + 2, jrow_of(has1 ? jp1 : jp), lane, 0, vb);
+    cb = load_cls8(A, (has1 ? lp1 : lp) + 2, jrow_of(has1 ? jp1 : jp), sl, 0);
+    int done = 0;
+    auto step = [&](double (&cur)[8], uint2& ccur, double (&far)[8], uint2& cfar) {
+        // request item + 8 into `far`, reduce `cur`
+        int lp2 = lp, jp2 = jp;
+        advance(lp2, jp2);
+        int lp3 = lp2, jp3 = jp2;
+        advance(lp3, jp3);
+        const bool more = (done + 2 < TABLE_IPW) && (item + 8 < n_items);
+        load_vals<true, HW>(A, (more ? lp3 : lp) + 2, jrow_of(more ? jp3 : jp), lane, 0, far);
+        cfar = load_cls8(A, (more ? lp3 : lp) + 2, jrow_of(more ? jp3 : jp), sl, 0);
+        table_row<HW, CH2>(A, lp + 2, lp, jrow_of(jp), A.gi0 + lp == L - 1, lane, cur, ccur);
+        item += 4; lp = lp2; jp = jp2; ++done;
+    };
+#pragma unroll 1
+    while (true) {
+        step(va, ca, vc, cc);
+        if (done >= TABLE_IPW || item >= n_items) break;
+        step(vb, cb, va, ca);
+        if (done >= TABLE_IPW || item >= n_items) break;
+        step(vc, cc, vb, cb);
+        if (done >= TABLE_IPW || item >= n_items) break;
+    }
+#else
+    double va[8], vb[8];
+    uint2 ca, cb;
+    load_vals<true, HW>(A, lp + 2, jrow_of(jp), lane, 0, va);
+    ca = load_cls8(A, lp + 2, jrow_of(jp), sl, 0);
+    // one item: `cur` holds its values on entry; the next item's are requested into `nxt` first (past the wave's last item
+    // the request repeats the current one: a cache hit)
+    auto step = [&](double (&cur)[8], uint2& ccur, double (&nxt)[8], uint2& cnxt, bool last) {
+        int lp2 = lp, jp2 = jp + 4;
+        while (jp2 >= ipp) { jp2 -= ipp; ++lp2; }
+        const bool more = !last && (item + 4 < n_items);
+        const int lpn = more ? lp2 : lp, jpn = more ? jp2 : jp;
+        load_vals<true, HW>(A, lpn + 2, jrow_of(jpn), lane, 0, nxt);
+        cnxt = load_cls8(A, lpn + 2, jrow_of(jpn), sl, 0);
+        table_row<HW, CH2>(A, lp + 2, lp, jrow_of(jp), A.gi0 + lp == L - 1, lane, cur, ccur);
+        item += 4; lp = lp2; jp = jp2;
+    };
+#pragma unroll 1
+    for (int t = 0; t < TABLE_IPW; t += 2) {
+        step(va, ca, vb, cb, false);
+        if (item >= n_items) break;
+        step(vb, cb, va, ca, t + 2 >= TABLE_IPW);
+        if (item >= n_items) break;
+    }
+#endif
+}
+
 // Exact incremental stepping: between two temperature updates an event changes the rates of a few rows
 // only (those holding the changed voxel(s) or one of their 14 neighbours).  k_apply_batch records those
 // rows; this kernel re-evaluates just them -- one wave per row, class bytes read straight from global
@@ -645,10 +858,15 @@ __global__ __launch_bounds__(256) void k_rows_eval(StreamArgs A, const int* __re
     if (w == 0) {
         const int li = lp + 2;
         const int jrow = (HW && lane >= 32) ? L_INACTIVE : j;       // the second half-wave idles
-        auto rowp = [&](int d, int dj) { return A.cls + ((int64_t)(li + d) * A.RJ + (j + 2 + dj)) * A.pitchC + KOFFC; };
         double v0[8];
         load_vals<TAB, HW>(A, li, jrow, lane, 0, v0);
-        sweep_row<TAB, HW, CH2>(A, rowp, li, lp, jrow, A.gi0 + lp == A.L - 1, lane, v0);
+        if (TAB) {          // the census-free row reduction of k_sweep_table: same bits
+            const uint2 c0 = load_cls8(A, li, jrow, HW ? (lane & 31) : lane, 0);
+            table_row<HW, CH2>(A, li, lp, jrow, A.gi0 + lp == A.L - 1, lane, v0, c0);
+        } else {
+            auto rowp = [&](int d, int dj) { return A.cls + ((int64_t)(li + d) * A.RJ + (j + 2 + dj)) * A.pitchC + KOFFC; };
+            sweep_row<TAB, HW, CH2>(A, rowp, li, lp, jrow, A.gi0 + lp == A.L - 1, lane, v0);
+        }
     }
     __syncthreads();
     // the block that finishes a plane's last dirty row reduces that plane's three category blocks (waves 0..2);
