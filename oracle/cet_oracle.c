@@ -724,16 +724,22 @@ static int window_select(const orc_params *P, int L, const int8_t *state, const 
 /* one box's pick on the given lattice copy (window origin i0,j0,k0, edge H, uniform u): exported for the multi-rank
  * protocol rehearsal (tests/test_dist_gloo.py), where every rank picks for its own boxes on its slab + halo copy.
  * Returns 1 for an idle box (ev->type == -1). */
-int orc_window_pick(const orc_params *P, int L, const int8_t *state, const double *theta, const double *phi,
-                    const double *T, const int8_t *defects, int i0, int j0, int k0, int H, double u, orc_event *ev)
+int orc_window_pick_r(const orc_params *P, int L, const int8_t *state, const double *theta, const double *phi,
+                      const double *T, const int8_t *defects, int i0, int j0, int k0, int H, double u, orc_event *ev,
+                      double *R_out /* window total (0 for an idle box); may be NULL */)
 {
     const int PH = next_pow2(H), PT = next_pow2(3 * H);
     const int64_t NL = (int64_t)PT * PH * PH;
     double *leaf = (double *)malloc(sizeof(double) * (size_t)NL);
     int32_t *lcnt = (int32_t *)malloc(sizeof(int32_t) * (size_t)NL);
-    const int idle = window_select(P, L, state, theta, phi, T, defects, i0, j0, k0, H, u, leaf, lcnt, ev, NULL);
+    const int idle = window_select(P, L, state, theta, phi, T, defects, i0, j0, k0, H, u, leaf, lcnt, ev, R_out);
     free(leaf); free(lcnt);
     return idle;
+}
+int orc_window_pick(const orc_params *P, int L, const int8_t *state, const double *theta, const double *phi,
+                    const double *T, const int8_t *defects, int i0, int j0, int k0, int H, double u, orc_event *ev)
+{
+    return orc_window_pick_r(P, L, state, theta, phi, T, defects, i0, j0, k0, H, u, ev, NULL);
 }
 
 int64_t orc_run_supersteps(const orc_params *P, int L, int8_t *state, double *theta, double *phi,

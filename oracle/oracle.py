@@ -203,11 +203,15 @@ class Lattice:
                                    C.c_double(r), C.byref(ev))
         return None if rc else ev
 
-    def window_pick(self, i0, j0, k0, H, u):
-        """Mode B: the pick of ONE box (window origin, edge H, uniform u) on this lattice copy; None for an idle box."""
+    def window_pick(self, i0, j0, k0, H, u, with_total=False):
+        """Mode B: the pick of ONE box (window origin, edge H, uniform u) on this lattice copy; None for an idle box.
+        with_total: (event or None, window total R_d) -- what the null-event acceptance compares with R_max."""
         ev = Event()
-        idle = lib().orc_window_pick(C.byref(self.params), self.L, *self._fields(), int(i0), int(j0), int(k0), int(H),
-                                     C.c_double(u), C.byref(ev))
+        R = C.c_double(0.0)
+        idle = lib().orc_window_pick_r(C.byref(self.params), self.L, *self._fields(), int(i0), int(j0), int(k0), int(H),
+                                       C.c_double(u), C.byref(ev), C.byref(R))
+        if with_total:
+            return (None if idle else ev), R.value
         return None if idle else ev
 
     def sweep(self):

@@ -194,7 +194,7 @@ def test_slab_protocol_world(oracle_mod, tmp_path, L, world):
 KEY_PICK, KEY_THETA, KEY_PHI, KEY_DEFECT = 1 << 40, 2 << 40, 3 << 40, 4 << 40
 
 
-def _worker_b(rank, world, port, L, box, n_steps, seed, df, out_dir):
+def _worker_b(rank, world, port, L, box, n_steps, seed, df, out_dir, null_events=False):
     """Protocol of cetkmc_run_supersteps across ranks (cetkmc_hip.hip), with the CPU oracle as the per-slab engine:
     per super-step (1) own row/block sums, all-gather, global total; (2) every rank picks for ITS boxes on its
     slab + halo copy; (3) the events of the bottom / top box layer go to the rank below / above (neighbour
@@ -238,12 +238,24 @@ def _worker_b(rank, world, port, L, box, n_steps, seed, df, out_dir):
         sec = g % 8
         si, sj, sk = (sec >> 2) & 1, (sec >> 1) & 1, sec & 1
         recs = np.zeros((D, 12))                       # valid, type, pos3, target3, atom, theta, phi, make_defect
+        picks = []
         for dl in range(D):
             d = d0 + dl
             di, dj, dk = d // nb2, (d // nb) % nb, d % nb
-            ev = lat.window_pick(di * box + si * H, dj * box + sj * H, dk * box + sk * H, H,
-                                 oracle.counter_uniform(seed, g, KEY_PICK | d))
+            picks.append(lat.window_pick(di * box + si * H, dj * box + sj * H, dk * box + sk * H, H,
+                                         oracle.counter_uniform(seed, g, KEY_PICK | d), with_total=True))
+        r_max = 0.0
+        if null_events:     # R_max over ALL ranks' boxes: one more small collective per super-step (the engine: 8-byte all-gather)
+            mine_max = torch.tensor([max([R for ev, R in picks if ev is not None], default=0.0)], dtype=torch.float64)
+            dist.all_reduce(mine_max, op=dist.ReduceOp.MAX)
+            r_max = float(mine_max[0])
+        for dl in range(D):
+            d = d0 + dl
+            ev, R_d = picks[dl]
             if ev is None:
+                continue
+            if null_events and not (oracle.counter_uniform(seed, g, oracle.KEY_ACCEPT | d) * r_max < R_d):
+                recs[dl, 0] = -2                       # null event: nothing drawn, nothing applied, nothing sent as an event
                 continue
             atom, th, ph = ev.atom, 0.0, 0.0
             if ev.type == 0:
@@ -286,25 +298,26 @@ def _worker_b(rank, world, port, L, box, n_steps, seed, df, out_dir):
                     upd = tgt
                 if v[11]:
                     put(upd, 4, 0.0, 0.0)
-        n_exec.append(int(recs[:, 0].sum()))
+        n_exec.append(int((recs[:, 0] == 1).sum()))
         log.append(recs[:, :9].copy())
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), state=lat.state[i0:i1], theta=lat.theta[i0:i1], phi=lat.phi[i0:i1],
              log=np.array(log), totals=np.array(totals), n_exec=np.array(n_exec))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("L,world,box", [(16, 2, 8), (24, 3, 8)])
-def test_mode_b_slab_protocol_world(oracle_mod, tmp_path, L, world, box):
+@pytest.mark.parametrize("L,world,box,null_events", [(16, 2, 8, False), (24, 3, 8, False), (16, 2, 8, True), (24, 3, 8, True)])
+def test_mode_b_slab_protocol_world(oracle_mod, tmp_path, L, world, box, null_events):
     n_steps, seed, df = 20, 11, 0.05
-    mp.spawn(_worker_b, args=(world, _free_port(), L, box, n_steps, seed, df, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker_b, args=(world, _free_port(), L, box, n_steps, seed, df, str(tmp_path), null_events), nprocs=world, join=True)
     state, theta, phi, T, defects = random_lattice(L, seed, fill=0.25)
     lat = oracle_mod.Lattice(state, theta, phi, T, defects, impurity_c=0.2)
-    res = lat.run_supersteps(0, n_steps, box, df, seed, thermal_mode=0)
+    res = lat.run_supersteps(0, n_steps, box, df, seed, thermal_mode=0, null_events=null_events)
     assert res["done"] == n_steps
     zs = [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]
     log = np.concatenate([z["log"] for z in zs], axis=1)             # [n][D global][9]
     live = log[:, :, 0] == 1
     assert np.array_equal(live, res["events"]["type"] >= 0)
+    assert np.array_equal(log[:, :, 0] == -2, res["events"]["type"] == -2) and ((log[:, :, 0] == -2).sum() > 0) == null_events
     assert np.array_equal(log[:, :, 1][live], res["events"]["type"][live])
     assert np.array_equal(log[:, :, 2:5][live], res["events"]["pos"][live])
     assert np.array_equal(log[:, :, 5:8][live], res["events"]["target"][live])
