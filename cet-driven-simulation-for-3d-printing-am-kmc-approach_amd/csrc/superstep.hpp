@@ -502,7 +502,10 @@ __global__ __launch_bounds__(256) CETKMC_TOUCH_ATTR void k_domain_touch(KParams 
         const double Tc = pymax(S.T[t], 1.0);
         double sum = 0.0;
         int cnt = 0;
-        if (st == 0) ifc_eval_empty(P, S, ktab, lp, aj, ak, t, code, Tc, sum, cnt);
+#ifndef CETKMC_TOUCH_BATCH
+#define CETKMC_TOUCH_BATCH 4
+#endif
+        if (st == 0) ifc_eval_empty<CETKMC_TOUCH_BATCH>(P, S, ktab, lp, aj, ak, t, code, Tc, sum, cnt);
         else if (st != 4) ifc_eval_atom(P, S, lp, aj, ak, t, code, st, Tc, sum, cnt);
         ifc_store(S, lp + 2, aj, ak, t, sum, cnt, code);
     }
