@@ -142,7 +142,9 @@ struct Handle {
     int thermal_general = 0;   // 1: k_thermal_march also where k_thermal_tiles applies (A/B, tests)
     int therm_ni = THERM_NI;   // planes per block of the marching kernel
     int therm_ni16 = THERM16_NI;   // planes per block of k_thermal_tiles16
-    int thermal_tiles16 = 0;   // 1: the 16-row k_thermal_tiles16 where tiles apply (A/B, tests: measured slower); 0: k_thermal_tiles
+    int thermal_rpt = 2;       // rows per thread of k_thermal_tiles16 (2: 1024 threads per block at 256 columns (default); 4: 512)
+    int thermal_kt = 256;      // columns per tile of k_thermal_tiles16 (256, or 128 with 2 rows per thread: 512 threads)
+    int thermal_tiles16 = 1;   // 1: the 16-row k_thermal_tiles16 where tiles apply (default); 0: the 8-row k_thermal_tiles (round-2 kernel)
     int ifc_blocks = 64;       // grid of k_interface (grid-stride over the device-side list length)
     int ifc_block = 256;
     size_t shmem_stream = 0;
@@ -817,10 +819,17 @@ int launch_thermal(Handle* h, double dt, int laser, const double* d_q, int use_l
             if (h->L % THERM_KT == 0 && h->L % THERM16_TJ == 0 && !h->thermal_general && h->thermal_tiles16) {   // 16-row tiles (option), covering the lattice exactly
                 ThermalCfg C16 = C;
                 C16.ni = h->therm_ni16;
-                dim3 g16(h->L / THERM_KT, h->L / THERM16_TJ, (v.nloc + C16.ni - 1) / C16.ni);
-                if (laser && use_latent) hipLaunchKernelGGL((k_thermal_tiles16<true, true>), g16, dim3(512), 0, h->stream, v, Tin, Tout, prev, d_q, C16, ssp);
-                else if (laser) hipLaunchKernelGGL((k_thermal_tiles16<true, false>), g16, dim3(512), 0, h->stream, v, Tin, Tout, prev, d_q, C16, ssp);
-                else hipLaunchKernelGGL((k_thermal_tiles16<false, false>), g16, dim3(512), 0, h->stream, v, Tin, Tout, prev, d_q, C16, ssp);
+                dim3 g16(h->L / h->thermal_kt, h->L / THERM16_TJ, (v.nloc + C16.ni - 1) / C16.ni);
+#define CETKMC_LAUNCH_T16(LA, LT)                                                                                                 \
+    do {                                                                                                                          \
+        if (h->thermal_rpt == 2 && h->thermal_kt == 128) hipLaunchKernelGGL((k_thermal_tiles16<LA, LT, 2, 128>), g16, dim3(512), 0, h->stream, v, Tin, Tout, prev, d_q, C16, ssp); \
+        else if (h->thermal_rpt == 2) hipLaunchKernelGGL((k_thermal_tiles16<LA, LT, 2, 256>), g16, dim3(1024), 0, h->stream, v, Tin, Tout, prev, d_q, C16, ssp); \
+        else hipLaunchKernelGGL((k_thermal_tiles16<LA, LT, 4, 256>), g16, dim3(512), 0, h->stream, v, Tin, Tout, prev, d_q, C16, ssp);   \
+    } while (0)
+                if (laser && use_latent) CETKMC_LAUNCH_T16(true, true);
+                else if (laser) CETKMC_LAUNCH_T16(true, false);
+                else CETKMC_LAUNCH_T16(false, false);
+#undef CETKMC_LAUNCH_T16
             } else if (h->L % THERM_KT == 0 && h->L % THERM_TJ == 0 && !h->thermal_general) {      // the 8-row tiles cover the lattice exactly
                 if (laser && use_latent) hipLaunchKernelGGL((k_thermal_tiles<true, true>), grid, dim3(256), 0, h->stream, v, Tin, Tout, prev, d_q, C, ssp);
                 else if (laser) hipLaunchKernelGGL((k_thermal_tiles<true, false>), grid, dim3(256), 0, h->stream, v, Tin, Tout, prev, d_q, C, ssp);
@@ -1137,11 +1146,14 @@ int cetkmc_set_option(void* handle, const char* key, int64_t value)
         return 0;
     }
     if (!strcmp(key, "thermal_variant")) {
-        // 0: one thread per voxel; 1 (default): plane marching -- k_thermal_tiles where the tiles cover the lattice exactly
-        // (L a multiple of 256), else k_thermal_march; 2: k_thermal_march everywhere; 3: like 1 with the 16-row k_thermal_tiles16
-        if (value < 0 || value > 3) return fail("thermal_variant must be 0 (simple), 1 (marching, default), 2 (marching, general kernel only) or 3 (marching, 16-row tiles)");
+        // 0: one thread per voxel; 1 (default): plane marching -- k_thermal_tiles16 (16 x 256 tiles, 1024 threads, 2 rows per
+        // thread) where the tiles cover the lattice exactly (L a multiple of 256), else k_thermal_march; 2: k_thermal_march
+        // everywhere; 3: 16-row tiles with 4 rows per thread (512 threads); 4: the 8-row k_thermal_tiles; 5: 16 x 128 tiles
+        if (value < 0 || value > 5) return fail("thermal_variant must be 0 (simple), 1 (marching, default: 16-row tiles, 2 rows per thread), 2 (marching, general kernel only), 3 (16-row tiles, 4 rows per thread), 4 (8-row tiles) or 5 (16-row x 128-column tiles)");
         h->thermal_general = value == 2 ? 1 : 0;
-        h->thermal_tiles16 = value == 3 ? 1 : 0;
+        h->thermal_tiles16 = value == 4 ? 0 : 1;
+        h->thermal_rpt = value == 3 ? 4 : 2;
+        h->thermal_kt = value == 5 ? 128 : 256;
         if (value >= 2) value = 1;
         h->thermal_variant = (int)value;
         return 0;

@@ -2232,34 +2232,39 @@ __global__ __launch_bounds__(256) CETKMC_THERM_ATTR void k_thermal_tiles(SlabVie
 //     stencil of plane i needs plane i+1's values, so with a one-plane distance the loads issued at the top of an iteration
 //     were awaited a few instructions later; now a whole iteration's arithmetic and barriers lie in between.
 // Same loads per voxel, same expression order, same bits (test_thermal_kernel_variants_identical).
-// MEASURED SLOWER than k_thermal_tiles in the real loop (laser + latent heat, 256^3: 84.6 us at 8 planes per block, 105 at 16,
-// against 79.7): the update is bound by latency under low occupancy, not by its re-reads.  Kept as
-// option thermal_variant = 3.
+// MEASURED in the real loop (laser + latent heat, 256^3, rocprofv3): with FOUR rows per thread (512 threads,
+// 128 VGPRs, 60 B of scratch in the latent instantiation) 84.6 us at 8 planes per block and 105 at 16 against 79.7 for the 8-row
+// k_thermal_tiles -- fewer bytes, but half the waves; with TWO rows per thread (1024 threads: half the plane registers, 96 VGPRs,
+// no scratch, one block = 16 waves per CU) 71.0 us at 16 planes per block: the default (thermal_variant 1).
 constexpr int THERM16_TJ = 16, THERM16_NI = 16;
 #ifndef CETKMC_THERM16_ATTR
 #define CETKMC_THERM16_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
 #endif
-template <bool LASER, bool LATENT>
-__global__ __launch_bounds__(512) CETKMC_THERM16_ATTR void k_thermal_tiles16(SlabView S, const double* __restrict__ Tin, double* __restrict__ Tout,
+// RPT = rows per thread (4 or 2: half the plane registers per thread), KT = columns per tile (256 or 128); threads per block =
+// (KT / 2) * (16 / RPT): 512 (4, 256), 1024 (2, 256) or 512 (2, 128: two blocks per CU at <= 128 VGPRs)
+template <bool LASER, bool LATENT, int RPT, int KT>
+__global__ __launch_bounds__((KT / 2) * (16 / RPT)) CETKMC_THERM16_ATTR void k_thermal_tiles16(SlabView S, const double* __restrict__ Tin, double* __restrict__ Tout,
                                                          uint8_t* __restrict__ prev_state, const double* __restrict__ q_top,
                                                          ThermalCfg C, const StepState* __restrict__ ss)
 {
-    constexpr int TJ = THERM16_TJ, KT = THERM_KT, LW = KT + 2;
+    constexpr int TJ = THERM16_TJ, LW = KT + 2, HC = KT / 2, NTHR = HC * (16 / RPT);
+    static_assert(NTHR >= 2 * KT, "one rim cell per thread");
     __shared__ double tile[(TJ + 2) * LW];
     const int L = S.L, pitchT = S.pitchT;
     const int tid = threadIdx.x;
     const int kc = blockIdx.x * KT, j0 = blockIdx.y * TJ;
     const int lp0 = blockIdx.z * C.ni, lp1 = min(lp0 + C.ni, S.nloc);
-    const int col = 2 * (tid & 127), rbase = tid >> 7;          // thread: columns kc+col, kc+col+1 of rows rbase+4q
+    constexpr int RS = TJ / RPT;                                // row stride of a thread's rows (= tid >> 7 range)
+    const int col = 2 * (tid % HC), rbase = tid / HC;           // thread: columns kc+col, kc+col+1 of rows rbase + RS q
     const int k0 = kc + col;
     const int64_t pstride = (int64_t)L * pitchT;
-    int off[4];                                                 // in-plane offsets of the thread's four column pairs
+    int off[RPT];                                               // in-plane offsets of the thread's column pairs
 #pragma unroll
-    for (int q = 0; q < 4; ++q) off[q] = (j0 + rbase + 4 * q) * pitchT + k0;
+    for (int q = 0; q < RPT; ++q) off[q] = (j0 + rbase + RS * q) * pitchT + k0;
     if (ss && ss->status) {                                     // terminated batch: the field is passed through unchanged
         for (int lp = lp0; lp < lp1; ++lp)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < RPT; ++q) {
                 const int64_t c = (int64_t)(lp + 2) * pstride + off[q];
                 *reinterpret_cast<double2*>(Tout + c) = *reinterpret_cast<const double2*>(Tin + c);
             }
@@ -2268,17 +2273,20 @@ __global__ __launch_bounds__(512) CETKMC_THERM16_ATTR void k_thermal_tiles16(Sla
     const int scrub = C.scrub;
     auto lplane = [&](int i) { return (i < 0 ? 0 : (i > L - 1 ? L - 1 : i)) - (S.gi0 - 2); };   // clamped global plane -> local
     // rim cells of a plane, one load per thread: threads 0..255 the row above the tile (j0-1), 256..511 the row below (j0+TJ);
-    // threads < 2 (TJ+2) additionally one cell of the two side columns -- all from clamped coordinates (= edge replication)
-    const int rim_col = tid & 255, rim_low = tid >> 8;
+    // 2 (TJ+2) threads (the first ones; with 1024 threads: 512..547) one cell of the two side columns -- all from clamped
+    // coordinates (= edge replication)
+    const int rim_col = tid % KT, rim_low = (tid / KT) & 1;
+    const bool has_rim = tid < 2 * KT;
     const int rim_off = (rim_low ? min(j0 + TJ, L - 1) : max(j0 - 1, 0)) * pitchT + kc + rim_col;
-    const int side_row = tid >> 1, side_right = tid & 1;
-    const bool has_side = tid < 2 * (TJ + 2);
+    const int stid = (NTHR >= 2 * KT + 2 * (TJ + 2)) ? tid - 2 * KT : tid;
+    const int side_row = stid >> 1, side_right = stid & 1;
+    const bool has_side = stid >= 0 && stid < 2 * (TJ + 2);
     const int side_off = min(max(j0 + side_row - 1, 0), L - 1) * pitchT + (side_right ? min(kc + KT, L - 1) : max(kc - 1, 0));
-    double prv[4][2], cur[4][2], nxt[4][2], nx2[4][2];
-    auto load_own = [&](int li, double (&dst)[4][2]) {
+    double prv[RPT][2], cur[RPT][2], nxt[RPT][2], nx2[RPT][2];
+    auto load_own = [&](int li, double (&dst)[RPT][2]) {
         const double* base = Tin + (int64_t)li * pstride;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < RPT; ++q) {
             const double2 v = *reinterpret_cast<const double2*>(base + off[q]);
             dst[q][0] = scrub_T(v.x, C.T_nan, scrub);
             dst[q][1] = scrub_T(v.y, C.T_nan, scrub);
@@ -2287,10 +2295,10 @@ __global__ __launch_bounds__(512) CETKMC_THERM16_ATTR void k_thermal_tiles16(Sla
     load_own(lplane(S.gi0 + lp0 - 1), prv);
     load_own(lp0 + 2, cur);
     load_own(lplane(S.gi0 + lp0 + 1), nxt);
-    double rr, rs = 0.0;
+    double rr = 0.0, rs = 0.0;
     {
         const double* plane = Tin + (int64_t)(lp0 + 2) * pstride;
-        rr = plane[rim_off];
+        if (has_rim) rr = plane[rim_off];
         if (has_side) rs = plane[side_off];
     }
     const double dtm = C.dt > 1e-12 ? C.dt : 1e-12;
@@ -2302,21 +2310,21 @@ __global__ __launch_bounds__(512) CETKMC_THERM16_ATTR void k_thermal_tiles16(Sla
         // After the block's last planes the (unconditional) requests repeat a plane the block has just read: cache hits
         load_own(lplane(min(i + 2, S.gi0 + lp1)), nx2);
         const double* plane_n = Tin + (int64_t)min(li + 1, lp1 + 1) * pstride;
-        const double rr_n = plane_n[rim_off];
-        double rs_n = 0.0;
+        double rr_n = 0.0, rs_n = 0.0;
+        if (has_rim) rr_n = plane_n[rim_off];
         if (has_side) rs_n = plane_n[side_off];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            double* row = tile + (rbase + 4 * q + 1) * LW + 1 + col;
+        for (int q = 0; q < RPT; ++q) {
+            double* row = tile + (rbase + RS * q + 1) * LW + 1 + col;
             row[0] = cur[q][0]; row[1] = cur[q][1];
         }
-        tile[(rim_low ? (TJ + 1) * LW : 0) + 1 + rim_col] = scrub_T(rr, C.T_nan, scrub);
+        if (has_rim) tile[(rim_low ? (TJ + 1) * LW : 0) + 1 + rim_col] = scrub_T(rr, C.T_nan, scrub);
         if (has_side) tile[side_row * LW + (side_right ? KT + 1 : 0)] = scrub_T(rs, C.T_nan, scrub);
         __syncthreads();
         const bool top = LASER && (i == L - 1);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = rbase + 4 * q, j = j0 + r;
+        for (int q = 0; q < RPT; ++q) {
+            const int r = rbase + RS * q, j = j0 + r;
             unsigned st2 = 0, pv2 = 0;
             if (LATENT && S.row_chg[(int64_t)li * L + j]) {      // wave-uniform (a wave's rows differ by q only)
                 const int64_t sc = S.sidx(li, j, k0);
@@ -2358,7 +2366,7 @@ __global__ __launch_bounds__(512) CETKMC_THERM16_ATTR void k_thermal_tiles16(Sla
         }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < RPT; ++q) {
             prv[q][0] = cur[q][0]; prv[q][1] = cur[q][1]; cur[q][0] = nxt[q][0]; cur[q][1] = nxt[q][1];
             nxt[q][0] = nx2[q][0]; nxt[q][1] = nx2[q][1];
         }

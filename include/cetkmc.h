@@ -218,8 +218,9 @@ int cetkmc_sync(void* handle);
  * whole interface list before every full sweep instead of only after a temperature update; "thermal_lookahead" 1 = the next
  * temperature update of a batch and its rate table are computed ahead on a second stream (single process; same bits;
  * default 0: measured slower); "thermal_variant" 0 = one thread per voxel, 1 = plane marching (default:
- * k_thermal_tiles where 8 x 256 tiles cover the lattice exactly, else k_thermal_march), 2 = k_thermal_march everywhere,
- * 3 = like 1 with the 16-row k_thermal_tiles16 (less traffic, measured slower: DESIGN.md section 13);
+ * k_thermal_tiles16 -- 16 x 256 tiles, 1024 threads with 2 rows each, 16 planes per block -- where the tiles cover the lattice
+ * exactly, else k_thermal_march), 2 = k_thermal_march everywhere, 3 = 16-row tiles with 4 rows per thread, 4 = the 8-row
+ * k_thermal_tiles (round-2 kernel), 5 = 16 x 128 tiles (A/B variants);
  * "thermal_planes_per_block" (march / 8-row tiles), "thermal_planes_per_block16" (16-row tiles); "reserve_batch" n = allocate the
  * device buffers and hipEvents of a batch of n steps now (a bench keeps hipMalloc / hipEventCreate out of its timed region) */
 int cetkmc_set_option(void* handle, const char* key, int64_t value);

@@ -384,10 +384,10 @@ def test_config2_constant_T_128(oracle_mod):
 
 @pytest.mark.parametrize("L,n_slabs", [(5, 1), (19, 2), (64, 1), (130, 3), (300, 1), (256, 1), (256, 4)])
 def test_thermal_kernel_variants_identical(L, n_slabs):
-    """Plane-marching LDS thermal kernels (1: k_thermal_tiles where the tiles cover the lattice exactly -- L = 256 here --
-    else k_thermal_march; 2: k_thermal_march everywhere; 3: the 16-row k_thermal_tiles16, also with 5 planes per block:
-    a march that does not divide the slab) == one-thread-per-voxel kernel, bit for bit (cet, laser with and without the
-    latent-heat term, NaN scrubbing)."""
+    """Plane-marching LDS thermal kernels (1: k_thermal_tiles16 with 2 rows per thread where the tiles cover the lattice
+    exactly -- L = 256 here -- else k_thermal_march; 2: k_thermal_march everywhere; 3: 16-row tiles with 4 rows per thread;
+    4: the 8-row k_thermal_tiles; 5: 16 x 128 tiles; 1x: the same with 5 planes per block, a march that does not divide the
+    slab) == one-thread-per-voxel kernel, bit for bit (cet, laser with and without the latent-heat term, NaN scrubbing)."""
     rs = np.random.RandomState(L)
     T = rs.uniform(2700.0, 4100.0, (L, L, L))
     T[rs.random_sample((L, L, L)) < 0.01] = np.nan
@@ -396,10 +396,10 @@ def test_thermal_kernel_variants_identical(L, n_slabs):
     q = rs.uniform(0, 1e15, (L, L))
     z = np.zeros((L, L, L))
     outs = []
-    for v in (0, 1, 2, 3, 13):
+    for v in (0, 1, 2, 3, 4, 5, 11, 13, 15):
         e = _engine(L, n_slabs=n_slabs)
         e.set_option("thermal_variant", v % 10)
-        if v == 13:
+        if v >= 11:
             e.set_option("thermal_planes_per_block16", 5)
         e.upload(state, z, z, T, state * 0)
         e.set_prev_state(prev)

@@ -11,9 +11,9 @@ e = cetkmc.Engine(L, impurity_c=0.2)
 st, th, ph, T, df = synthetic.planes(L, 0, L, seed=42)
 e.upload_planes(0, L, st, th, ph, T, df)
 q = synthetic.laser_planes(L, 0, 1)[0]
-for variant, ni in ((1, 4), (1, 8), (3, 4), (3, 8), (3, 16), (3, 32), (2, 4)):
+for variant, ni in ((4, 4), (4, 8), (1, 8), (1, 16), (1, 32), (3, 16), (5, 16), (2, 4)):
     e.set_option("thermal_variant", variant)
-    e.set_option("thermal_planes_per_block16" if variant == 3 else "thermal_planes_per_block", ni)
+    e.set_option("thermal_planes_per_block" if variant in (2, 4) else "thermal_planes_per_block16", ni)
     for mode in ("cet", "laser"):
         ts = []
         for rep in range(6):

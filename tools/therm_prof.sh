@@ -9,7 +9,7 @@ for spec in "$@"; do
   v=${spec%%:*}; ni=${spec#*:}
   opts="--set-option thermal_variant=$v"
   if [ "$ni" != "$spec" ]; then
-    if [ "$v" = "3" ]; then opts="$opts --set-option thermal_planes_per_block16=$ni"; else opts="$opts --set-option thermal_planes_per_block=$ni"; fi
+    if [ "$v" = "1" ] || [ "$v" = "3" ] || [ "$v" = "5" ]; then opts="$opts --set-option thermal_planes_per_block16=$ni"; else opts="$opts --set-option thermal_planes_per_block=$ni"; fi
   fi
   d=$OUT/thprof_${v}_${ni}
   rm -rf $d

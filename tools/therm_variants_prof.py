@@ -15,8 +15,10 @@ st, th, ph, T, df = synthetic.planes(L, 0, L, seed=42)
 e.upload_planes(0, L, st, th, ph, T, df)
 e.set_prev_state(None)
 q = synthetic.laser_planes(L, 0, 1)[0]
-for variant in (1, 3):
+for variant, ni in ((1, 16), (3, 16), (4, 4), (5, 16)):
     e.set_option("thermal_variant", variant)
+    e.set_option("thermal_planes_per_block" if variant == 4 else "thermal_planes_per_block16", ni)
+    e.sync()
     for rep in range(12):
         e.thermal_cet(1e-6, True)
         e.thermal_laser(1e-6, q, use_latent=False)
