@@ -59,7 +59,7 @@ for which in ("fetch", "write"):
         summary["kernels"].setdefault(name, {})[f"{which}_size_kb_median"] = statistics.median(v)
 for name, k in summary["kernels"].items():
     if "fetch_size_kb_median" in k and "write_size_kb_median" in k:
-        wide = name in ("k_sweep_stream", "k_sweep_stream_recompute", "k_rate_table", "k_thermal", "k_thermal_march", "k_thermal_tiles")
+        wide = name in ("k_sweep_stream", "k_sweep_stream_recompute", "k_rate_table", "k_thermal", "k_thermal_march", "k_thermal_tiles", "k_thermal_tiles16")
         k["hbm_bytes_per_launch"] = (2.0 if wide else 1.0) * k["fetch_size_kb_median"] * 1024 + k["write_size_kb_median"] * 1024
         k["fetch_x2_applied"] = wide
 modes = one(f"{tag}_stats_modes/*/*kernel_stats.csv")
