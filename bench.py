@@ -407,16 +407,23 @@ def main():
     inc = guarded("incremental_exact", do_incremental) if (not a.no_incremental and (N == 1 or a.extras_multi)) else None
 
     # ---- Mode B (super-steps over 8^3 boxes; not the reference's trajectory, own CPU comparator): executed events/s
-    def do_mode_b(null_events):
+    def do_mode_b(null_events, const_T=None):
         nb_steps, nb_warm = 40, 8
+        tm = 2
+        if const_T is not None:
+            # the same lattice under a STATIONARY, uniform temperature field (config 2's field; no melt pool, no updates): the
+            # regime Mode B's null events are meant for -- every rate within a few decades, acceptance of the order of one half
+            a0_, a1_ = max(0, eng.i0 - 2), min(L, eng.i1 + 2)
+            eng.upload_planes(a0_, a1_, T=np.full((a1_ - a0_, L, L), float(const_T)))
+            tm = 0
         # untimed warm-up (first launch of the Mode B kernels loads their code objects: ~10 ms once per process)
-        rw = eng.run_supersteps(st["step"], nb_warm, 8, DEFECT_FRACTION, seed=SEED, thermal_mode=2,
-                                q_planes=synthetic.laser_planes(L, st["step"], nb_warm), null_events=null_events)
+        rw = eng.run_supersteps(st["step"], nb_warm, 8, DEFECT_FRACTION, seed=SEED, thermal_mode=tm,
+                                q_planes=synthetic.laser_planes(L, st["step"], nb_warm) if tm == 2 else None, null_events=null_events)
         st["step"] += rw["done"]
-        qb = synthetic.laser_planes(L, st["step"], nb_steps)
+        qb = synthetic.laser_planes(L, st["step"], nb_steps) if tm == 2 else None
         barrier()
         t2 = time.perf_counter()
-        rb = eng.run_supersteps(st["step"], nb_steps, 8, DEFECT_FRACTION, seed=SEED, thermal_mode=2, q_planes=qb,
+        rb = eng.run_supersteps(st["step"], nb_steps, 8, DEFECT_FRACTION, seed=SEED, thermal_mode=tm, q_planes=qb,
                                 null_events=null_events)
         barrier()
         dtb = allreduce(time.perf_counter() - t2, "MAX")
@@ -432,6 +439,9 @@ def main():
             mode_b = {"executed_events_per_s": n_exec / dtb, "ms_per_superstep": 1e3 * dtb / nb_steps,
                       "events_per_superstep": n_exec / nb_steps, "boxes": (L // 8) ** 3, "supersteps": nb_steps,
                       "warmup_supersteps": nb_warm, "null_events": bool(null_events),
+                      "temperature_field": "moving melt pool (update_temperature every 20 super-steps)" if const_T is None else
+                                           f"stationary, uniform {float(const_T):.0f} K (no updates)",
+                      "acceptance": n_exec / nb_steps / max(1.0, allreduce(float(n_own_b) / 512.0, "SUM")),
                       "simulated_time_per_superstep_s": float(np.mean(rb["dt_event"] * rb["n_exec"])) if len(rb["n_exec"]) else None,
                       "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
                                    "alg_bytes_per_superstep": alg,
@@ -470,6 +480,8 @@ def main():
     mode_b_ok = not a.no_mode_b and L % 8 == 0 and (L // N) % 8 == 0
     mode_b = guarded("mode_b", lambda: do_mode_b(False)) if mode_b_ok else None
     mode_b_null = guarded("mode_b_null_events", lambda: do_mode_b(True)) if mode_b_ok else None
+    # (last: it replaces the temperature field)
+    mode_b_null_ct = guarded("mode_b_null_events_stationary_T", lambda: do_mode_b(True, const_T=3000.0)) if mode_b_ok else None
 
     ev_over_ms = guarded("event_overhead", lambda: eng.event_overhead(50))
 
@@ -580,6 +592,7 @@ def main():
         "executed_events_per_s_incremental": inc["steps_per_s"] if inc else None,
         "executed_events_per_s_mode_b": mode_b["executed_events_per_s"] if mode_b else None,
         "executed_events_per_s_mode_b_null_events": mode_b_null["executed_events_per_s"] if mode_b_null else None,
+        "executed_events_per_s_mode_b_null_events_stationary_T": mode_b_null_ct["executed_events_per_s"] if mode_b_null_ct else None,
         "candidate_events_per_s": cand / dt,
         "candidate_events_per_step": cand / a.steps, "voxel_updates_per_s": float(L) ** 3 * steps_per_s,
         "device_ms_per_step": r["wall_ms"] / a.steps,
@@ -665,6 +678,8 @@ def main():
         out["mode_b"] = mode_b
     if mode_b_null is not None:
         out["mode_b_null_events"] = mode_b_null
+    if mode_b_null_ct is not None:
+        out["mode_b_null_events_stationary_T"] = mode_b_null_ct
     if dist is not None:
         box = [None] * N
         dist.all_gather_object(box, {"rank": rank, "owned_planes": [eng.i0, eng.i1], "sweep_avg_launch_ms": sweep_ms,
