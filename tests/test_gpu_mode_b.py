@@ -189,9 +189,11 @@ def test_supersteps_full_size_properties(oracle_mod):
     e.close()
 
 
-def test_supersteps_vs_oracle_128(oracle_mod):
-    """128^3, box 8 (4096 boxes), 10 super-steps = all eight octants + a temperature update: per-box events,
-    executed counts and every field equal the CPU comparator's."""
+@pytest.mark.parametrize("null_events", [False, True])
+def test_supersteps_vs_oracle_128(oracle_mod, null_events):
+    """128^3, box 8 (4096 boxes), 10 super-steps = all eight octants + a temperature update: per-box events (incl. the null
+    events of the acceptance test against R_max over 4096 window totals), executed counts and every field equal the CPU
+    comparator's."""
     import os
 
     import cetkmc
@@ -202,19 +204,20 @@ def test_supersteps_vs_oracle_128(oracle_mod):
     e = cetkmc.Engine(L, impurity_c=0.2, n_slabs=2)
     e.upload_planes(0, L, st, th, ph, T, df)
     e.set_prev_state(None)
-    rg = e.run_supersteps(15, n, box, 3e-3, seed=77, thermal_mode=2, q_planes=q, want_events=True)
+    rg = e.run_supersteps(15, n, box, 3e-3, seed=77, thermal_mode=2, q_planes=q, want_events=True, null_events=null_events)
     d = e.download()
     e.close()
     oracle_mod.set_threads(min(16, os.cpu_count() or 1))
     try:
         lat = oracle_mod.Lattice(st.astype(np.int64), th, ph, T, df.astype(np.int64), impurity_c=0.2)
-        ro = lat.run_supersteps(15, n, box, 3e-3, 77, thermal_mode=2, q_planes=q)
+        ro = lat.run_supersteps(15, n, box, 3e-3, 77, thermal_mode=2, q_planes=q, null_events=null_events)
     finally:
         oracle_mod.set_threads(1)
     assert rg["done"] == ro["done"] == n
     for f in ("type", "pos", "target", "atom"):
         assert np.array_equal(rg["events"][f], ro["events"][f]), f
-    assert np.array_equal(rg["n_exec"], ro["n_exec"]) and rg["n_exec"].min() > 2000
+    assert np.array_equal(rg["n_exec"], ro["n_exec"]) and (null_events or rg["n_exec"].min() > 2000)
+    assert (ro["events"]["type"] == -2).any() == null_events
     assert relerr(rg["totals"], ro["totals"]).max() <= RATE_RTOL
     assert np.array_equal(d["state"], lat.state) and np.array_equal(d["T"], lat.T)
     assert np.array_equal(d["theta"], lat.theta) and np.array_equal(d["phi"], lat.phi)
