@@ -756,7 +756,9 @@ def test_config5_workload_at_size(oracle_mod):
 def test_thermal_lookahead_option_identical(n_slabs, thermal_mode):
     """thermal_lookahead=1: the next temperature update of a batch and its rate table are computed ahead on a second
     stream without the latent-heat term; at the update k_thermal_fix recomputes the voxels the term concerns.  Must not
-    change a bit (events, totals, T, every field), also when the batch terminates early and across batches."""
+    change a bit (events, totals, T, every field), across batches that start off the 20-step cadence and through a Mode B
+    batch.  (Batches that stop early -- status 1 / 2 -- and their continuation are covered by
+    test_batch_that_runs_out_of_stream_continues_bit_identically and test_terminated_batch_leaves_a_consistent_engine.)"""
     import cetkmc
     from cetkmc import synthetic
     L, n = 48, 130
