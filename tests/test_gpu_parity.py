@@ -838,15 +838,18 @@ def _consumed_before(events, upto):
     return int(2 * np.isin(events["type"][:upto], (0, 2)).sum())
 
 
-@pytest.mark.parametrize("thermal_mode,incremental,n_slabs", [(1, False, 1), (2, False, 2), (1, True, 1), (2, True, 1)])
+@pytest.mark.parametrize("thermal_mode,incremental,n_slabs,lookahead", [(1, False, 1, 0), (2, False, 2, 0), (1, True, 1, 0), (2, True, 1, 0),
+                                                                        (2, False, 1, 1), (2, True, 1, 1)])
 @pytest.mark.parametrize("stop_at", [25, 40, 60])
-def test_batch_that_runs_out_of_stream_continues_bit_identically(oracle_mod, thermal_mode, incremental, n_slabs, stop_at):
+def test_batch_that_runs_out_of_stream_continues_bit_identically(oracle_mod, thermal_mode, incremental, n_slabs, lookahead, stop_at):
     """A batch whose NumPy stream runs short stops with status 2; the steps still queued behind the stop run as
     pass-throughs on the device while the host keeps flipping the temperature buffers and freshness flags.  The
     continuation must (a) sweep from a rate table of the CURRENT field (stop_at = 25: an odd number -- one, step 40's --
     of skipped temperature updates follow the stop; the table / deposition buffers are paired with the buffer parity) and
     (b) not apply a temperature update twice when the stream ran out ON an update step (stop_at = 40, 60: the update of
     that step ran before the selection noticed the shortage; kmc_simulation.py:248-250 updates T once per 20 steps).
+    lookahead = 1: the same with the look-ahead temperature update (second stream, k_thermal_fix and its pass-through
+    when the batch has stopped).
     Compared with one unbroken batch (bitwise: events, totals, every field) and with the oracle."""
     from cetkmc import synthetic
     L, n = 32, 50 if stop_at < 50 else 70
@@ -856,6 +859,7 @@ def test_batch_that_runs_out_of_stream_continues_bit_identically(oracle_mod, the
     q = synthetic.laser_planes(L, 0, n) if thermal_mode == 2 else None
     kw = dict(rng_mode=1, seed=21, thermal_mode=thermal_mode, incremental=incremental)
     ref = _fresh_engine(L, st, th, ph, T, df, n_slabs)
+    ref.set_option("thermal_lookahead", lookahead)
     r0 = ref.run_steps(0, n, 0.05, u_pick, u_def, u_np, q_planes=q, **kw)
     assert r0["done"] == n and r0["status"] == 0
     d0 = ref.download_planes(0, L, state=True, theta=True, phi=True, T=True)
@@ -864,6 +868,7 @@ def test_batch_that_runs_out_of_stream_continues_bit_identically(oracle_mod, the
     # the same run, the first call given a stream that ends right before step `stop_at` needs its two orientation slots
     cap = _consumed_before(r0["events"], stop_at) + 1
     e = _fresh_engine(L, st, th, ph, T, df, n_slabs)
+    e.set_option("thermal_lookahead", lookahead)
     r1 = e.run_steps(0, n, 0.05, u_pick, u_def, u_np[:cap], q_planes=q, **kw)
     assert r1["status"] == 2 and r1["done"] == stop_at and r1["np_used"] == cap - 1
     q2 = synthetic.laser_planes(L, stop_at, n - stop_at) if thermal_mode == 2 else None
