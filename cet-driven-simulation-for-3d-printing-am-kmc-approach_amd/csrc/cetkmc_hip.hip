@@ -608,7 +608,7 @@ int launch_dirty_rows(Handle* h, hipEvent_t ev_a, hipEvent_t ev_b)
         const int* dl = h->d_dirty;
         int* pc = h->d_dirty + 1 + DIRTY_MAX;
         const StepState* ss = h->d_ss;
-        const bool tab = h->sweep_variant == 1 || h->sweep_variant == 3, hw = h->Pk <= 256, ch2 = h->Pk > 512;
+        const bool tab = h->sweep_variant == 1 || h->sweep_variant >= 3, hw = h->Pk <= 256, ch2 = h->Pk > 512;
 #define CETKMC_LAUNCH_ROWS(TAB, HW, CH2) \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows_eval<TAB, HW, CH2>), dim3(24), dim3(256), 0, h->stream, sa, dl, ss, h->d_blocks, pc)
         if (hw) { if (tab) CETKMC_LAUNCH_ROWS(true, true, false); else CETKMC_LAUNCH_ROWS(false, true, false); }
@@ -652,7 +652,22 @@ int launch_sweep(Handle* h, bool batch, hipEvent_t ev_a = nullptr, hipEvent_t ev
     if (ev_a && !ext) HIPCHK(hipEventRecord(ev_a, h->stream));
     for (size_t s = 0; s < h->slabs.size(); ++s) {
         SlabView v = view_of(h, (int)s);
-        if (h->sweep_variant == 3) {
+        if (h->sweep_variant == 4) {
+            // census-free table sweep, one 16-wave block per owned plane, block sums folded in the same launch
+            const StreamArgs sa = stream_args(h, v);
+            const bool hw = h->Pk <= 256, ch2 = h->Pk > 512;
+            const dim3 g((unsigned)v.nloc);
+            const uint32_t shm = (uint32_t)(3 * h->L * (sizeof(double) + sizeof(int)));
+#define CETKMC_LAUNCH_PLANE(HW, CH2)                                                                                             \
+    do {                                                                                                                         \
+        if (ext) hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_plane<HW, CH2>), g, dim3(1024), shm, h->stream, ev_a, ev_b, 0, sa, ss, h->d_blocks); \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_plane<HW, CH2>), g, dim3(1024), shm, h->stream, sa, ss, h->d_blocks);     \
+    } while (0)
+            if (hw) CETKMC_LAUNCH_PLANE(true, false);
+            else if (!ch2) CETKMC_LAUNCH_PLANE(false, false);
+            else CETKMC_LAUNCH_PLANE(false, true);
+#undef CETKMC_LAUNCH_PLANE
+        } else if (h->sweep_variant == 3) {
             // census-free table sweep: class bytes + rate table streamed once, no LDS
             const StreamArgs sa = stream_args(h, v);
             const bool hw = h->Pk <= 256, ch2 = h->Pk > 512;
@@ -691,10 +706,11 @@ int launch_sweep(Handle* h, bool batch, hipEvent_t ev_a = nullptr, hipEvent_t ev
         }
     }
     if (ev_b && !ext) HIPCHK(hipEventRecord(ev_b, h->stream));
-    for (size_t s = 0; s < h->slabs.size(); ++s) {
-        SlabView v = view_of(h, (int)s);
-        hipLaunchKernelGGL(k_plane_reduce, dim3(3 * v.nloc), dim3(64), 0, h->stream, v, h->d_blocks, ss);
-    }
+    if (h->sweep_variant != 4)          // (variant 4 folds the block sums in the sweep launch)
+        for (size_t s = 0; s < h->slabs.size(); ++s) {
+            SlabView v = view_of(h, (int)s);
+            hipLaunchKernelGGL(k_plane_reduce, dim3(3 * v.nloc), dim3(64), 0, h->stream, v, h->d_blocks, ss);
+        }
     HIPCHK(hipGetLastError());
     if (multi_rank(h)) CHK(comm_allgather(h, h->d_blocks, (size_t)3 * (h->L / h->nranks) * sizeof(BlockEnt)));
     if (ev_post) HIPCHK(hipEventRecord(ev_post, h->stream));
@@ -1105,7 +1121,7 @@ int cetkmc_set_option(void* handle, const char* key, int64_t value)
     Handle* h = (Handle*)handle;
     if (!h || !key) return fail("null argument");
     if (!strcmp(key, "sweep_variant")) {
-        if (value < 0 || value > 3) return fail("sweep_variant must be 0 (simple), 1 (streaming + rate table, default), 2 (streaming, recompute) or 3 (census-free table sweep)");
+        if (value < 0 || value > 4) return fail("sweep_variant must be 0 (simple), 1 (streaming + rate table, default), 2 (streaming, recompute), 3 (census-free table sweep) or 4 (census-free, one block per plane, block sums in the same launch)");
         h->sweep_variant = (int)value;
         h->swept = false; h->table_fresh = false; h->ifc_fresh = false;
         return 0;

@@ -660,7 +660,7 @@ __device__ __forceinline__ uint2 load_cls8(const StreamArgs& A, int li, int jrow
 }
 template <bool HW, bool CH2>
 __device__ __forceinline__ void table_row(const StreamArgs& A, int li, int lp, int jrow, bool top, int lane, const double (&v0)[8],
-                                          uint2 own0)
+                                          uint2 own0, double* lds_sum = nullptr, int* lds_cnt = nullptr /* [3][L] of the block's plane */)
 {
     static_assert(!(HW && CH2), "half-wave rows have one chunk");
     const int L = A.L;
@@ -753,6 +753,10 @@ __device__ __forceinline__ void table_row(const StreamArgs& A, int li, int lp, i
         const int64_t o = (int64_t)lp * 3 * L + jrow;
         A.rowsum[o] = r0; A.rowsum[o + L] = r1; A.rowsum[o + 2 * (int64_t)L] = r2;
         A.rowcnt[o] = n0; A.rowcnt[o + L] = n1; A.rowcnt[o + 2 * (int64_t)L] = n2;
+        if (lds_sum) {
+            lds_sum[jrow] = r0; lds_sum[L + jrow] = r1; lds_sum[2 * L + jrow] = r2;
+            lds_cnt[jrow] = n0; lds_cnt[L + jrow] = n1; lds_cnt[2 * L + jrow] = n2;
+        }
     }
 }
 
@@ -834,6 +838,65 @@ __global__ __launch_bounds__(256) CETKMC_SWEEP_ATTR void k_sweep_table(StreamArg
         if (item >= n_items) break;
     }
 #endif
+}
+
+// k_sweep_plane (variant 4): k_sweep_table with one block per owned plane (16 waves; wave w takes the plane's items w, w + 16, ...),
+// which therefore holds all of the plane's row sums when its last row is done: the three block sums (balanced tree over j,
+// exactly plane_reduce_wave()) are folded from LDS by three of its waves -- no k_plane_reduce launch, no hand-off between
+// workgroups.  Same bits as variants 1 / 3 (+ k_plane_reduce).
+template <bool HW, bool CH2>
+__global__ __launch_bounds__(1024) CETKMC_SWEEP_ATTR void k_sweep_plane(StreamArgs A, const StepState* __restrict__ ss, BlockEnt* __restrict__ blocks)
+{
+    if (ss && ss->status) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int L = A.L;
+    double* lds_sum = reinterpret_cast<double*>(smem);                  // [3][L]
+    int* lds_cnt = reinterpret_cast<int*>(lds_sum + 3 * L);             // [3][L]
+    const int ipp = HW ? (L + 1) >> 1 : L;                              // items per plane (HW: pairs of rows)
+    int lp = blockIdx.x;
+    if ((gridDim.x & 7) == 0) lp = (lp & 7) * (int)(gridDim.x >> 3) + (lp >> 3);      // contiguous plane ranges per XCD
+    const int sl = HW ? (lane & 31) : lane;
+    auto jrow_of = [&](int jpair) { return HW ? 2 * jpair + (lane >> 5) : jpair; };
+    const bool top = A.gi0 + lp == L - 1;
+    int jp = w;
+    if (jp < ipp) {
+        double va[8], vb[8];
+        uint2 ca, cb;
+        load_vals<true, HW>(A, lp + 2, jrow_of(jp), lane, 0, va);
+        ca = load_cls8(A, lp + 2, jrow_of(jp), sl, 0);
+        auto step = [&](double (&cur)[8], uint2& ccur, double (&nxt)[8], uint2& cnxt) {
+            const int jpn = (jp + 16 < ipp) ? jp + 16 : jp;             // past the wave's last item: the current one again (cache hit)
+            load_vals<true, HW>(A, lp + 2, jrow_of(jpn), lane, 0, nxt);
+            cnxt = load_cls8(A, lp + 2, jrow_of(jpn), sl, 0);
+            table_row<HW, CH2>(A, lp + 2, lp, jrow_of(jp), top, lane, cur, ccur, lds_sum, lds_cnt);
+            jp += 16;
+        };
+#pragma unroll 1
+        while (true) {
+            step(va, ca, vb, cb);
+            if (jp >= ipp) break;
+            step(vb, cb, va, ca);
+            if (jp >= ipp) break;
+        }
+    }
+    __syncthreads();
+    if (w < 3) {        // block sum of (plane lp, category w): balanced tree over j, zeros beyond L -- plane_reduce_wave() on the LDS copy
+        const int nch = A.Pk > 64 ? (A.Pk >> 6) : 1;
+        double stk[5];
+        double tot = 0.0;
+        int64_t cnt = 0;
+        for (int m = 0; m < nch; ++m) {
+            const int j = (m << 6) + lane;
+            double v = 0.0;
+            int cv = 0;
+            if (j < L) { v = lds_sum[w * L + j]; cv = lds_cnt[w * L + j]; }
+            v = wave_tree_sum(v);
+            cnt += wave_sum_i(cv);
+            tot = stack_push(stk, v, m);
+        }
+        if (lane == 0) { blocks[3 * (A.gi0 + lp) + w].sum = tot; blocks[3 * (A.gi0 + lp) + w].cnt = cnt; }
+    }
 }
 
 // Exact incremental stepping: between two temperature updates an event changes the rates of a few rows

@@ -88,7 +88,8 @@ def test_sweep_vs_oracle_larger(oracle_mod, L, seed):
 @pytest.mark.parametrize("L,seed,fill", [(24, 1, 0.3), (40, 2, 0.05), (70, 3, 0.5), (8, 4, 0.9)])
 def test_sweep_variants_bit_identical(L, seed, fill):
     """The LDS-census streaming kernel with the rate table (1, default), the census-free table sweep (3: class bytes + rate
-    table only), the one that recomputes the nucleation rates per sweep (2) and the simple kernel (0) produce identical row
+    table only; 4: the same with one block per plane and the block sums folded in the sweep launch), the one that recomputes
+    the nucleation rates per sweep (2) and the simple kernel (0) produce identical row
     sums, also after events were applied (interface-list / rate-table / count-byte maintenance by the apply kernel: the
     table sweep trusts the event counts in the class bytes)."""
     state, theta, phi, T, defects = random_lattice(L, seed, fill=fill)
@@ -97,7 +98,7 @@ def test_sweep_variants_bit_identical(L, seed, fill):
     rs = np.random.RandomState(seed)
     for rnd in range(3):
         out = []
-        for v in (1, 2, 0, 3):
+        for v in (1, 2, 0, 3, 4):
             e.set_option("sweep_variant", v)
             info = e.rate_sweep()
             out.append((info,) + e.row_sums())
@@ -433,7 +434,7 @@ def test_large_L_two_chunks_per_row(L):
     q = synthetic.laser_planes(L, 0, n)
     u_pick, u_def, u_np = rs.random_sample(n), rs.random_sample(n), rs.random_sample(2 * n + 2)
     outs = []
-    for ns, variant in ((1, 1), (1, 0), (3, 1), (2, 2), (2, 3)):
+    for ns, variant in ((1, 1), (1, 0), (3, 1), (2, 2), (2, 3), (1, 4), (3, 4)):
         e = cetkmc.Engine(L, impurity_c=0.2, n_slabs=ns)
         e.set_option("sweep_variant", variant)
         e.upload_planes(0, L, st, th, ph, T, df)
@@ -487,7 +488,7 @@ def test_stream_kernel_row_shapes(L):
         e.set_prev_state(None)
         del st, th, ph, T, df
     out = []
-    for v in (1, 2, 0, 3):
+    for v in (1, 2, 0, 3, 4):
         e.set_option("sweep_variant", v)
         out.append((e.rate_sweep(),) + e.row_sums())
     for o in out[1:]:

@@ -13,7 +13,7 @@ import cetkmc  # noqa: E402
 from cetkmc import synthetic  # noqa: E402
 
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else "1,3".split(","))]
+variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else "1,3,4".split(","))]
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 e = cetkmc.Engine(L, impurity_c=0.2)
 fill = float(os.environ.get("FILL", "0.25"))
