@@ -132,6 +132,8 @@ struct Handle {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
     bool swept = false;
+    int sweep_auto = 1;        // sweep_variant never set explicitly: lattices of L <= 128 take variant 4 (launch-bound there: one launch
+                               // less per sweep; same bits), larger ones variant 1
     int sweep_variant = 1;     // 0 simple, 1 streaming + rate table with the LDS census (default), 2 streaming, nucleation rates
                                // recomputed per sweep, 3 census-free table sweep (same bits, measured no faster: DESIGN.md section 13)
     bool table_fresh = false;  // vval / dep_val match the current T and parameters (k_rate_table)
@@ -650,9 +652,10 @@ int launch_sweep(Handle* h, bool batch, hipEvent_t ev_a = nullptr, hipEvent_t ev
     // stream, so the timed steps run like untimed ones.  Several slabs in one process / the phase table: plain records.
     const bool ext = ev_a && ev_b && !ev_pre && h->slabs.size() == 1 && h->sweep_variant >= 1;
     if (ev_a && !ext) HIPCHK(hipEventRecord(ev_a, h->stream));
+    const int sv = (h->sweep_auto && h->sweep_variant == 1 && h->L <= 128) ? 4 : h->sweep_variant;      // effective sweep kernel
     for (size_t s = 0; s < h->slabs.size(); ++s) {
         SlabView v = view_of(h, (int)s);
-        if (h->sweep_variant == 4) {
+        if (sv == 4) {
             // census-free table sweep, one 16-wave block per owned plane, block sums folded in the same launch
             const StreamArgs sa = stream_args(h, v);
             const bool hw = h->Pk <= 256, ch2 = h->Pk > 512;
@@ -667,7 +670,7 @@ int launch_sweep(Handle* h, bool batch, hipEvent_t ev_a = nullptr, hipEvent_t ev
             else if (!ch2) CETKMC_LAUNCH_PLANE(false, false);
             else CETKMC_LAUNCH_PLANE(false, true);
 #undef CETKMC_LAUNCH_PLANE
-        } else if (h->sweep_variant == 3) {
+        } else if (sv == 3) {
             // census-free table sweep: class bytes + rate table streamed once, no LDS
             const StreamArgs sa = stream_args(h, v);
             const bool hw = h->Pk <= 256, ch2 = h->Pk > 512;
@@ -706,7 +709,7 @@ int launch_sweep(Handle* h, bool batch, hipEvent_t ev_a = nullptr, hipEvent_t ev
         }
     }
     if (ev_b && !ext) HIPCHK(hipEventRecord(ev_b, h->stream));
-    if (h->sweep_variant != 4)          // (variant 4 folds the block sums in the sweep launch)
+    if (sv != 4)          // (variant 4 folds the block sums in the sweep launch)
         for (size_t s = 0; s < h->slabs.size(); ++s) {
             SlabView v = view_of(h, (int)s);
             hipLaunchKernelGGL(k_plane_reduce, dim3(3 * v.nloc), dim3(64), 0, h->stream, v, h->d_blocks, ss);
@@ -1123,6 +1126,7 @@ int cetkmc_set_option(void* handle, const char* key, int64_t value)
     if (!strcmp(key, "sweep_variant")) {
         if (value < 0 || value > 4) return fail("sweep_variant must be 0 (simple), 1 (streaming + rate table, default), 2 (streaming, recompute), 3 (census-free table sweep) or 4 (census-free, one block per plane, block sums in the same launch)");
         h->sweep_variant = (int)value;
+        h->sweep_auto = 0;          // an explicit choice stands at every lattice size
         h->swept = false; h->table_fresh = false; h->ifc_fresh = false;
         return 0;
     }

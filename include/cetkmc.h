@@ -215,7 +215,8 @@ int cetkmc_sync(void* handle);
 /* tuning / A-B switches: "sweep_variant" 0 = simple kernel, 1 = streaming kernel (LDS census) + per-voxel rate table (default),
  * 2 = streaming kernel that recomputes the nucleation rates in every sweep, 3 = census-free table sweep (class bytes + rate table
  * streamed once, no LDS; same bits, measured no faster -- DESIGN.md section 13), 4 = the same with one block per plane and the block
- * sums folded in the sweep launch (no k_plane_reduce; faster at L <= 128 only); "interface_every_step" 1 = evaluate the
+ * sums folded in the sweep launch (no k_plane_reduce; faster at L <= 128 only -- which is why handles on which this option was
+ * never set use it for L <= 128 and variant 1 above); "interface_every_step" 1 = evaluate the
  * whole interface list before every full sweep instead of only after a temperature update; "thermal_lookahead" 1 = the next
  * temperature update of a batch and its rate table are computed ahead on a second stream (single process; same bits;
  * default 0: measured slower); "thermal_variant" 0 = one thread per voxel, 1 = plane marching (default:
