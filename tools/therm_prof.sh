@@ -15,5 +15,12 @@ for spec in "$@"; do
   rm -rf $d
   rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 $B --L ${THERM_L:-256} --steps 200 --warmup 20 --no-cpu-baseline --no-incremental --no-mode-b --no-phases --no-recompute --no-512 $opts > /dev/null 2>&1
   f=$(ls $d/*/*kernel_stats.csv | head -1)
-  echo "== variant $spec"; grep -E "k_thermal|k_rate_table|k_sweep_stream" $f | awk -F, '{printf "   %-60s calls %s avg_us %.2f min_us %.2f\n", substr($1,1,60), $2, $4/1000, $6/1000}'
+  echo "== variant $spec"
+  python3 - "$f" <<'PY'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    n = r["Name"]
+    if any(k in n for k in ("k_thermal", "k_rate_table", "k_sweep_stream")):
+        print("   %-60s calls %s avg_us %.2f min_us %.2f" % (n[:60], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3))
+PY
 done
