@@ -322,6 +322,7 @@ def run_kmc(
         if ckpt:
             ex = ckpt["extra"]
             if {k: ex.get(k) for k in mb_cfg} != mb_cfg:
+                engine.close()
                 raise ValueError(f"checkpoint was written by a run with {ex}, this call asks for {mb_cfg}")
             executed, g, thermal_done = next_step, int(ex["superstep"]), int(ex["thermal_done"])
         by_events = thermal_cadence == "events" and thermal_updates
