@@ -88,6 +88,52 @@ def cpu_baseline(L, fields, n_gpu_events, budget_s=15.0):
     return dict(steps=done, events=ev, n_events=nev, legs=legs)
 
 
+def live_traffic(L, steps=20, timeout=240):
+    """The sweep kernel's memory-side traffic per launch, measured in THIS run: two child runs of this script (the same
+    full-sweep loop, a few steps) under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` -- separate passes, counters only,
+    the program itself right behind `--` (MI355X_MICROARCH.md, HBM section).  Called BEFORE this process touches the GPU.
+    bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB -> B): on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads, which is
+    what the streaming sweep issues (tools/summarize_profiles.py applies the same correction to the committed profiles).
+    Returns (bytes per launch or None, provenance / reason)."""
+    import csv
+    import shutil
+    import statistics
+    import subprocess
+    import tempfile
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "already running under a profiler"
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    med = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="cetkmc_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", "python3", os.path.abspath(__file__),
+                   "--L", str(L), "--steps", str(steps), "--warmup", "2", "--no-cpu-baseline", "--no-incremental", "--no-mode-b",
+                   "--no-phases", "--no-recompute", "--no-512", "--no-live-traffic"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL, timeout=timeout)
+            files = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} child run failed (rc {r.returncode})"
+            vals = []
+            for row in csv.DictReader(open(files[0])):
+                head = row["Kernel_Name"].split("(")[0]
+                if "k_sweep_stream<true" in head:               # the rate-table sweep of the timed loop
+                    vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, f"no k_sweep_stream<table> launch in the {counter} pass"
+            med[counter] = statistics.median(vals)
+        except Exception as ex:                                    # noqa: BLE001 -- a failed side measurement must not cost the run
+            return None, f"rocprofv3 --pmc {counter} child run: {ex!r}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return (2.0 * med["FETCH_SIZE"] + med["WRITE_SIZE"]) * 1024.0, \
+        (f"this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of the same loop ({steps} steps), median over the sweep "
+         "launches, 2 x FETCH_SIZE + WRITE_SIZE (KB); Infinity-Cache hits are included (memory-side requests of the L2)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,6 +148,8 @@ def main():
     ap.add_argument("--no-mode-b", action="store_true", help="skip the extra Mode B (super-step) run")
     ap.add_argument("--no-phases", action="store_true", help="skip the extra per-phase timing run")
     ap.add_argument("--no-recompute", action="store_true", help="skip the extra run of the recompute sweep variant")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="skip the two rocprofv3 --pmc child runs that measure the sweep kernel's memory traffic in this run (N = 1)")
     ap.add_argument("--no-512", action="store_true",
                     help="skip the extra 512^3 single-GPU sweep measurement (working set 1.2 GB: no Infinity-Cache residency)")
     ap.add_argument("--transport", choices=["rccl", "host"], default="rccl",
@@ -132,6 +180,16 @@ def main():
         cfg_name, scaling = "config4", "strong"        # the 256^3 lattice of config 3, split
     else:
         cfg_name, scaling = "config3-weak", "weak"
+
+    # memory traffic of the dominant kernel, measured now (child runs under rocprofv3 --pmc) -- before this process owns the GPU
+    live_bytes, live_src = (None, "not requested")
+    if N == 1 and world == 1 and not a.no_live_traffic and not config5 and not a.force_dist:
+        live_bytes, live_src = live_traffic(L)
+        if live_bytes is None:
+            print(f"bench: live traffic measurement skipped ({live_src})", file=sys.stderr)
+    live512_bytes, live512_src = (None, "not requested")
+    if live_bytes is not None and L == 256 and not a.no_512:      # the cache-free leg's traffic too (hbm_512 below)
+        live512_bytes, live512_src = live_traffic(512, steps=6)
 
     # Libraries chat on stdout (gloo's "[Gloo] Rank ..." line, RCCL's version banner under NCCL_DEBUG): keep fd 1 for
     # the ONE JSON line -- everything else goes to stderr until the result is printed.
@@ -525,10 +583,14 @@ def main():
                 break
         except Exception:
             pass
+    summary_src = traffic_src                 # the committed profile (kernel averages; traffic too unless measured in this run)
+    traffic_live = live_bytes is not None
+    if traffic_live:
+        traffic, traffic_src = live_bytes, live_src
     if phases is not None and rocprof_kernels:
         per_update = sum(rocprof_kernels.get(k, 0.0) for k in ("k_thermal_tiles", "k_thermal_march", "k_rate_table", "k_interface", "k_clear_row_flags"))
         phases["rocprof"] = {
-            "kernel_avg_us": rocprof_kernels, "source": traffic_src,
+            "kernel_avg_us": rocprof_kernels, "source": summary_src,
             "select_apply_plus_reduce_plus_interface_us_per_step":
                 rocprof_kernels.get("k_select_apply", 0.0) + rocprof_kernels.get("k_plane_reduce", 0.0) + rocprof_kernels.get("k_interface", 0.0) / 20,
             "per_update_work_us_per_step": per_update / 20,
@@ -558,6 +620,8 @@ def main():
                     "alg_bytes_per_launch": B_ALG_SWEEP * nv5, "achieved": ach5, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": ach5 / HBM_PEAK_GBS,
                     "working_set_bytes": int(B_ALG_SWEEP * nv5), "fits_infinity_cache": False,
                     "device_ms_per_step": rr["wall_ms"] / n5,
+                    "traffic": live512_bytes, "traffic_measured_in_run": live512_bytes is not None, "traffic_source": live512_src,
+                    "traffic_over_algorithmic": (live512_bytes / (B_ALG_SWEEP * nv5)) if live512_bytes else None,
                     "note": "measured live in this run on the same GPU; committed trace + PMC of the same workload: profiles/r03_512_*"}
         finally:
             e5.close()
@@ -614,14 +678,16 @@ def main():
                                     "achieved": (B_ALG_SWEEP + 32.0 / 20.0) * n_own / (r["wall_ms"] / a.steps * 1e-3) / 1e9,
                                     "frac": (B_ALG_SWEEP + 32.0 / 20.0) * n_own / (r["wall_ms"] / a.steps * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                     "unit": "GB/s"},
-                     "traffic_measured_in_run": False,
+                     "traffic_measured_in_run": traffic_live,
+                     "traffic_over_algorithmic": (traffic / (B_ALG_SWEEP * n_own)) if traffic else None,
                      "avg_launch_ms": sweep_ms, "launches_timed": int(r["sweep_launches"]),
                      "timing": "hipEvent pairs attached to the sweep launches of the timed region (hipExtLaunchKernelGGL start / "
                                "stop events on the engine's stream; several slabs per process: hipEventRecord around the launches)",
                      # what two hipEventRecord calls add around a launch (measured in this run around an empty kernel): the
                      # phase table's boundaries and multi-slab handles are timed that way, the sweep launches above are not
                      "event_pair_overhead_ms": ev_over_ms,       # two records around an EMPTY kernel (its ~3.5 us included)
-                     "rocprof_avg_launch_ms": rocprof_ms,        # committed kernel trace of the same command (traffic_source)
+                     "rocprof_avg_launch_ms": rocprof_ms,        # committed kernel trace of the same command
+                     "rocprof_source": summary_src,
                      "frac_rocprof": (B_ALG_SWEEP * n_own / (rocprof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if rocprof_ms else None,
                      "launches_in_timed_region": int(r["full_sweeps"]),
                      "alg_bytes_per_voxel": B_ALG_SWEEP, "voxels_per_launch": n_own,

@@ -3,7 +3,7 @@
 # Usage on the GPU box: bash tools/pmc512.sh base ni16 notail
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 B=$GRAFT_REPO_ROOT/bench.py
-LOOP="--L ${PMC_L:-512} --steps 20 --warmup 2 --no-cpu-baseline --no-incremental --no-mode-b --no-phases --no-recompute --no-512"
+LOOP="--L ${PMC_L:-512} --steps 20 --warmup 2 --no-cpu-baseline --no-incremental --no-mode-b --no-phases --no-recompute --no-512 --no-live-traffic"
 cd /tmp && export TMPDIR=/tmp
 for tag in "$@"; do
   if [ "$tag" = "base" ]; then unset CETKMC_LIB; else export CETKMC_LIB=$GRAFT_REPO_ROOT/cet-driven-simulation-for-3d-printing-am-kmc-approach_amd/csrc/libcetkmc_hip_$tag.so; fi

@@ -9,7 +9,7 @@ TAG=${1:-r03}
 PARTS=${2:-"bench stats pmc modes 512"}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 B=$GRAFT_REPO_ROOT/bench.py
-LOOP="--no-cpu-baseline --no-incremental --no-mode-b --no-phases --no-recompute --no-512"
+LOOP="--no-cpu-baseline --no-incremental --no-mode-b --no-phases --no-recompute --no-512 --no-live-traffic"
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 has() { case " $PARTS " in *" $1 "*) return 0;; *) return 1;; esac; }
@@ -20,10 +20,10 @@ if has pmc; then
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -- python3 $B --steps 40 --warmup 4 $LOOP > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -- python3 $B --steps 40 --warmup 4 $LOOP > /dev/null 2>&1; echo "pmc done"; fi
 if has modes; then
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats_modes -- python3 $B --steps 400 --warmup 40 --no-cpu-baseline --no-512 > $OUT/${TAG}_bench_modes_under_rocprof.json 2> /dev/null; echo "modes done"; fi
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats_modes -- python3 $B --steps 400 --warmup 40 --no-cpu-baseline --no-512 --no-live-traffic > $OUT/${TAG}_bench_modes_under_rocprof.json 2> /dev/null; echo "modes done"; fi
 if has modespmc; then
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_modes_pmc_fetch -- python3 $B --steps 40 --warmup 4 --no-cpu-baseline --no-512 --no-phases --no-recompute --no-incremental > /dev/null 2>&1
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_modes_pmc_write -- python3 $B --steps 40 --warmup 4 --no-cpu-baseline --no-512 --no-phases --no-recompute --no-incremental > /dev/null 2>&1; echo "modespmc done"; fi
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_modes_pmc_fetch -- python3 $B --steps 40 --warmup 4 --no-cpu-baseline --no-512 --no-live-traffic --no-phases --no-recompute --no-incremental > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_modes_pmc_write -- python3 $B --steps 40 --warmup 4 --no-cpu-baseline --no-512 --no-live-traffic --no-phases --no-recompute --no-incremental > /dev/null 2>&1; echo "modespmc done"; fi
 if has 512; then
   T5=${TAG}_512
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${T5}_stats -- python3 $B --L 512 --steps 60 --warmup 6 $LOOP > $OUT/${T5}_bench_under_rocprof.json 2> /dev/null

@@ -13,7 +13,7 @@ for spec in "$@"; do
   fi
   d=$OUT/thprof_${v}_${ni}
   rm -rf $d
-  rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 $B --L ${THERM_L:-256} --steps 200 --warmup 20 --no-cpu-baseline --no-incremental --no-mode-b --no-phases --no-recompute --no-512 $opts > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 $B --L ${THERM_L:-256} --steps 200 --warmup 20 --no-cpu-baseline --no-incremental --no-mode-b --no-phases --no-recompute --no-512 --no-live-traffic $opts > /dev/null 2>&1
   f=$(ls $d/*/*kernel_stats.csv | head -1)
   echo "== variant $spec"
   python3 - "$f" <<'PY'

@@ -7,7 +7,7 @@ for tag in "$@"; do
   if [ "$tag" = "default" ]; then unset CETKMC_LIB; else export CETKMC_LIB=$GRAFT_REPO_ROOT/cet-driven-simulation-for-3d-printing-am-kmc-approach_amd/csrc/libcetkmc_hip_$tag.so; fi
   d=$OUT/touchprof_$tag
   rm -rf $d
-  rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 $B --steps 100 --warmup 20 --no-cpu-baseline --no-incremental --no-phases --no-recompute --no-512 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 $B --steps 100 --warmup 20 --no-cpu-baseline --no-incremental --no-phases --no-recompute --no-512 --no-live-traffic > /dev/null 2>&1
   f=$(ls $d/*/*kernel_stats.csv | head -1)
   echo "== build $tag"
   python3 - "$f" <<'PY'
