@@ -88,7 +88,7 @@ def cpu_baseline(L, fields, n_gpu_events, budget_s=15.0):
     return dict(steps=done, events=ev, n_events=nev, legs=legs)
 
 
-def live_traffic(L, steps=20, timeout=240):
+def live_traffic(L, steps=20, timeout=90):
     """The sweep kernel's memory-side traffic per launch, measured in THIS run: two child runs of this script (the same
     full-sweep loop, a few steps) under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` -- separate passes, counters only,
     the program itself right behind `--` (MI355X_MICROARCH.md, HBM section).  Called BEFORE this process touches the GPU.
@@ -112,11 +112,19 @@ def live_traffic(L, steps=20, timeout=240):
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", "python3", os.path.abspath(__file__),
                    "--L", str(L), "--steps", str(steps), "--warmup", "2", "--no-cpu-baseline", "--no-incremental", "--no-mode-b",
                    "--no-phases", "--no-recompute", "--no-512", "--no-live-traffic"]
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
-                               stderr=subprocess.DEVNULL, timeout=timeout)
+            # its own process group: a pass that does not end in time is removed together with the program it started
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                                    stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = proc.wait(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(proc.pid, signal.SIGKILL)
+                proc.wait()
+                return None, f"rocprofv3 --pmc {counter} child run did not end within {timeout} s"
             files = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
-            if r.returncode != 0 or not files:
-                return None, f"rocprofv3 --pmc {counter} child run failed (rc {r.returncode})"
+            if rc != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} child run failed (rc {rc})"
             vals = []
             for row in csv.DictReader(open(files[0])):
                 head = row["Kernel_Name"].split("(")[0]
