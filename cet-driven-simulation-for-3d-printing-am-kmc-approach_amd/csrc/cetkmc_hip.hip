@@ -180,6 +180,13 @@ struct Handle {
                                  // the look-ahead kernels run right behind the update, beside the next sweeps, which they slow down
                                  // by more than the update costs (both are memory bound, and they evict the sweep's working set)
     hipEvent_t ev_main = nullptr, ev_spec = nullptr;
+    // cetkmc_run_supersteps' working buffers (grow-only: run_kmc(mode="B") under the event-count thermal clock makes one call
+    // per super-step, which five hipMalloc / hipFree pairs per call would dominate)
+    cetkmc_event* d_sup_dom = nullptr; size_t cap_sup_dom = 0;
+    DomPick* d_sup_picks = nullptr; size_t cap_sup_picks = 0;
+    unsigned long long* d_sup_cnt = nullptr; size_t cap_sup_cnt = 0;
+    cetkmc_event* d_sup_log = nullptr; size_t cap_sup_log = 0;
+    double* d_sup_rmax = nullptr; size_t cap_sup_rmax = 0;
 };
 
 KParams make_kparams(const cetkmc_params& p)
@@ -991,7 +998,7 @@ void destroy_impl(Handle* h)
     for (void* p : ccp) if (p) (void)hipFree(p);
     void* ptrs[] = {h->d_views[0], h->d_views[1], h->d_blocks, h->d_events_all, h->d_ss, h->d_dirty, h->d_ktab, h->d_kp, h->d_scratch,
                     h->d_flag, h->d_qtop, h->d_u_pick, h->d_u_defect, h->d_u_np, h->d_q, h->d_log_total,
-                    h->d_log_event, h->d_log_nev};
+                    h->d_log_event, h->d_log_nev, h->d_sup_dom, h->d_sup_picks, h->d_sup_cnt, h->d_sup_log, h->d_sup_rmax};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
@@ -1740,34 +1747,25 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
         h->cap_steps = std::min({c1, c2, c3, c4, c5});
         if (a->thermal_mode == 2) CHK(grow(&h->d_q, &h->cap_q, (size_t)std::max<int64_t>(n_therm, 1) * L2));
     }
-    // per-call device buffers, released on every return path
-    struct Tmp {
-        cetkmc_event* dom = nullptr; DomPick* picks = nullptr; unsigned long long* cnt = nullptr; cetkmc_event* log = nullptr;
-        double* rmax = nullptr;
-        ~Tmp() { (void)hipFree(dom); (void)hipFree(picks); (void)hipFree(cnt); (void)hipFree(log); (void)hipFree(rmax); }
-    } tmp;
-    double*& d_rmax = tmp.rmax;
-    HIPCHK(hipMalloc((void**)&d_rmax, (size_t)std::max(C.nranks, 1) * sizeof(double)));
+    // working buffers of the handle (grow-only; the previous call ended with a synchronisation, nothing still reads them)
+    CHK(grow(&h->d_sup_rmax, &h->cap_sup_rmax, (size_t)std::max(C.nranks, 1)));
+    CHK(grow(&h->d_sup_dom, &h->cap_sup_dom, (size_t)NE));
+    CHK(grow(&h->d_sup_picks, &h->cap_sup_picks, (size_t)D));
+    CHK(grow(&h->d_sup_cnt, &h->cap_sup_cnt, (size_t)SUPER_CNT_SLOTS * SUPER_CNT_STRIDE));
+    if (events && n > 0) CHK(grow(&h->d_sup_log, &h->cap_sup_log, (size_t)n * D));
+    double* const d_rmax = h->d_sup_rmax;
+    cetkmc_event* const d_dom = h->d_sup_dom;
+    DomPick* const d_picks = h->d_sup_picks;
+    unsigned long long* const d_cnt = h->d_sup_cnt;
+    cetkmc_event* const d_log = (events && n > 0) ? h->d_sup_log : nullptr;
     HIPCHK(hipMemsetAsync(d_rmax, 0, (size_t)std::max(C.nranks, 1) * sizeof(double), h->stream));
-    cetkmc_event*& d_dom = tmp.dom;
-    DomPick*& d_picks = tmp.picks;
-    unsigned long long*& d_cnt = tmp.cnt;
-    cetkmc_event*& d_log = tmp.log;
-    HIPCHK(hipMalloc((void**)&d_dom, (size_t)NE * sizeof(cetkmc_event)));
     HIPCHK(hipMemsetAsync(d_dom, 0xFF, (size_t)NE * sizeof(cetkmc_event), h->stream));      // type -1: nothing received
-    HIPCHK(hipMalloc((void**)&d_picks, (size_t)D * sizeof(DomPick)));
     const size_t cnt_bytes = (size_t)SUPER_CNT_SLOTS * SUPER_CNT_STRIDE * sizeof(unsigned long long);
-    HIPCHK(hipMalloc((void**)&d_cnt, cnt_bytes));
-    if (events && n > 0) HIPCHK(hipMalloc((void**)&d_log, (size_t)n * D * sizeof(cetkmc_event)));
     HIPCHK(hipMemsetAsync(d_cnt, 0, cnt_bytes, h->stream));
     if (a->thermal_mode == 2 && n_therm > 0)
         HIPCHK(hipMemcpyAsync(h->d_q, a->q_planes, (size_t)n_therm * L2 * 8, hipMemcpyHostToDevice, h->stream));
     StepState ss;
-    HIPCHK(hipMemcpyAsync(&ss, h->d_ss, sizeof ss, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    ss.cur = 0; ss.status = 0; ss.np_pos = 0; ss.min_margin = 1.0;
-    HIPCHK(hipMemcpyAsync(h->d_ss, &ss, sizeof ss, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    hipLaunchKernelGGL(k_batch_reset, dim3(1), dim3(1), 0, h->stream, h->d_ss);     // the batch part of the step state, on the stream
     BatchCfg cfg{};
     cfg.step0 = a->step0; cfg.np_cap = 0; cfg.defect_fraction = a->defect_fraction; cfg.seed = a->seed;
     cfg.rng_mode = 1; cfg.batch = 1;
@@ -1833,13 +1831,13 @@ int cetkmc_run_supersteps(void* handle, const cetkmc_super_args* a, cetkmc_run_r
     if (ss.status != 0) { h->table_fresh = false; h->ifc_fresh = false; h->swept = false; }     // as in cetkmc_run_steps
     CHK(refresh_ifc_grid(h));
     const int64_t done = ss.cur;
-    if (totals && done > 0) HIPCHK(hipMemcpy(totals, h->d_log_total, (size_t)done * 8, hipMemcpyDeviceToHost));
-    if (totals && ss.status == 1 && done < n) totals[done] = ss.total;
-    if (dt_event && done > 0) {
+    if ((totals || dt_event) && done > 0) {
         std::vector<double> tot((size_t)done);
         HIPCHK(hipMemcpy(tot.data(), h->d_log_total, (size_t)done * 8, hipMemcpyDeviceToHost));
-        for (int64_t s = 0; s < done; ++s) dt_event[s] = superstep_dt_event(a->seed, a->step0 + s, tot[(size_t)s]);
+        if (totals) memcpy(totals, tot.data(), (size_t)done * 8);
+        if (dt_event) for (int64_t s = 0; s < done; ++s) dt_event[s] = superstep_dt_event(a->seed, a->step0 + s, tot[(size_t)s]);
     }
+    if (totals && ss.status == 1 && done < n) totals[done] = ss.total;
     if (n_executed && done > 0) HIPCHK(hipMemcpy(n_executed, h->d_log_nev, (size_t)done * 8, hipMemcpyDeviceToHost));
     if (events && done > 0) HIPCHK(hipMemcpy(events, d_log, (size_t)done * D * sizeof(cetkmc_event), hipMemcpyDeviceToHost));
     return 0;
