@@ -176,6 +176,7 @@ struct Handle {
     // (the thermal kernels run before the selection notices the shortage).  The continuation batch starts at the same
     // global step: it must not apply the update a second time (kmc_simulation.py:248-250 updates T once per 20 steps).
     int64_t therm_applied_g = -1;
+    int thermal_table = 1;       // option "thermal_table": the default temperature tiles write the rate table too (no k_rate_table launch)
     int thermal_ahead = 0;       // option "thermal_lookahead": off by default -- measured slower on one GPU:
                                  // the look-ahead kernels run right behind the update, beside the next sweeps, which they slow down
                                  // by more than the update costs (both are memory bound, and they evict the sweep's working set)
@@ -834,6 +835,7 @@ int launch_thermal(Handle* h, double dt, int laser, const double* d_q, int use_l
     ++h->cnt.thermal_updates;
     for (auto& sl : h->slabs) h->cnt.alg_bytes_thermal += (int64_t)16 * sl.v.nloc * h->L * h->L;   // T read + written
     const int nxt = h->cur ^ 1;
+    size_t n_fused = 0;
     for (size_t s = 0; s < h->slabs.size(); ++s) {
         SlabView v = view_of(h, (int)s);
         if (h->thermal_variant == 1) {
@@ -846,11 +848,19 @@ int launch_thermal(Handle* h, double dt, int laser, const double* d_q, int use_l
                 ThermalCfg C16 = C;
                 C16.ni = h->therm_ni16;
                 dim3 g16(h->L / h->thermal_kt, h->L / THERM16_TJ, (v.nloc + C16.ni - 1) / C16.ni);
+                // the default tiles also write the new field's rate table (k_rate_table's work, without reading T again)
+                const bool fuse = h->thermal_table && h->thermal_rpt == 2 && h->thermal_kt == 256 && h->sweep_variant >= 1;
+                TableCfg TB{};
+                TB.T_melt = h->kp.T_melt; TB.delta_T_c = h->kp.delta_T_c; TB.kT = h->kp.kT; TB.I0 = h->kp.I0;
+                TB.rate_threshold = h->kp.rate_threshold; TB.K0 = host_k_eff(h->p, 0, 0); TB.nu_dep = h->kp.nu_dep;
+                TB.vval = h->slabs[s].vvalbuf[nxt]; TB.dep_val = h->slabs[s].depbuf[nxt];
+                if (fuse) { ++n_fused; h->cnt.alg_bytes_table += (int64_t)8 * v.nloc * v.L * v.L; }      // table entry written (T not re-read)
 #define CETKMC_LAUNCH_T16(LA, LT)                                                                                                 \
     do {                                                                                                                          \
-        if (h->thermal_rpt == 2 && h->thermal_kt == 128) hipLaunchKernelGGL((k_thermal_tiles16<LA, LT, 2, 128>), g16, dim3(512), 0, h->stream, v, Tin, Tout, prev, d_q, C16, ssp); \
-        else if (h->thermal_rpt == 2) hipLaunchKernelGGL((k_thermal_tiles16<LA, LT, 2, 256>), g16, dim3(1024), 0, h->stream, v, Tin, Tout, prev, d_q, C16, ssp); \
-        else hipLaunchKernelGGL((k_thermal_tiles16<LA, LT, 4, 256>), g16, dim3(512), 0, h->stream, v, Tin, Tout, prev, d_q, C16, ssp);   \
+        if (fuse) hipLaunchKernelGGL((k_thermal_tiles16<LA, LT, 2, 256, true>), g16, dim3(1024), 0, h->stream, v, Tin, Tout, prev, d_q, C16, ssp, TB); \
+        else if (h->thermal_rpt == 2 && h->thermal_kt == 128) hipLaunchKernelGGL((k_thermal_tiles16<LA, LT, 2, 128>), g16, dim3(512), 0, h->stream, v, Tin, Tout, prev, d_q, C16, ssp, TableCfg{}); \
+        else if (h->thermal_rpt == 2) hipLaunchKernelGGL((k_thermal_tiles16<LA, LT, 2, 256>), g16, dim3(1024), 0, h->stream, v, Tin, Tout, prev, d_q, C16, ssp, TableCfg{}); \
+        else hipLaunchKernelGGL((k_thermal_tiles16<LA, LT, 4, 256>), g16, dim3(512), 0, h->stream, v, Tin, Tout, prev, d_q, C16, ssp, TableCfg{});   \
     } while (0)
                 if (laser && use_latent) CETKMC_LAUNCH_T16(true, true);
                 else if (laser) CETKMC_LAUNCH_T16(true, false);
@@ -882,7 +892,8 @@ int launch_thermal(Handle* h, double dt, int laser, const double* d_q, int use_l
     }
     h->cur = nxt;
     h->swept = false;
-    h->table_fresh = false;
+    h->table_fresh = n_fused == h->slabs.size();      // every slab's update wrote its table as well
+    if (h->table_fresh) { h->ifc_fresh = false; ++h->cnt.table_updates; }       // the listed voxels' entries follow (k_interface)
     h->therm_applied_g = -1;
     return 0;
 }
@@ -1149,6 +1160,7 @@ int cetkmc_set_option(void* handle, const char* key, int64_t value)
         return 0;
     }
     if (!strcmp(key, "thermal_lookahead")) { h->thermal_ahead = value ? 1 : 0; return 0; }
+    if (!strcmp(key, "thermal_table")) { h->thermal_table = value ? 1 : 0; return 0; }
     if (!strcmp(key, "reserve_batch")) {
         // device buffers (uniform streams, per-step logs, one laser source plane per temperature update) and hipEvents of a
         // batch of `value` steps, allocated ahead of it: a bench keeps hipMalloc / hipEventCreate out of its timed region

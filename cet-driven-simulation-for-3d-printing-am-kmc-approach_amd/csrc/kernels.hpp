@@ -1915,6 +1915,12 @@ struct ThermalCfg {
     double dt, alpha, inv_dx2, clip_lo, clip_hi, T_nan, rho_cp, latent_coef;
     int laser, use_latent, scrub, ni;
 };
+// the rate table's inputs, for the temperature kernel that writes the table entry of every voxel it updates (k_thermal_tiles16<.., TABLE>)
+struct TableCfg {
+    double T_melt, delta_T_c, kT, I0, rate_threshold, K0, nu_dep;
+    double* vval;       // the NEW field's table (the buffer pair is flipped with T)
+    double* dep_val;
+};
 __device__ __forceinline__ double scrub_T(double x, double T_nan, int on)
 {   // np.nan_to_num(T, nan=T_SUB), kmc_simulation.py:249
     if (!on) return x;
@@ -2305,10 +2311,13 @@ constexpr int THERM16_TJ = 16, THERM16_NI = 16;
 #endif
 // RPT = rows per thread (4 or 2: half the plane registers per thread), KT = columns per tile (256 or 128); threads per block =
 // (KT / 2) * (16 / RPT): 512 (4, 256), 1024 (2, 256) or 512 (2, 128: two blocks per CU at <= 128 VGPRs)
-template <bool LASER, bool LATENT, int RPT, int KT>
+// TABLE: the kernel also writes what k_rate_table would compute from the new field -- the rate table entry of every voxel it
+// updates (and plane L-1's deposition rates) -- while the new temperature is still in a register: the field is not read a
+// second time (16 of the pair's 32 B per voxel saved).  Same functions on the same values: same bits.
+template <bool LASER, bool LATENT, int RPT, int KT, bool TABLE = false>
 __global__ __launch_bounds__((KT / 2) * (16 / RPT)) CETKMC_THERM16_ATTR void k_thermal_tiles16(SlabView S, const double* __restrict__ Tin, double* __restrict__ Tout,
                                                          uint8_t* __restrict__ prev_state, const double* __restrict__ q_top,
-                                                         ThermalCfg C, const StepState* __restrict__ ss)
+                                                         ThermalCfg C, const StepState* __restrict__ ss, TableCfg TB = TableCfg{})
 {
     constexpr int TJ = THERM16_TJ, LW = KT + 2, HC = KT / 2, NTHR = HC * (16 / RPT);
     static_assert(NTHR >= 2 * KT, "one rim cell per thread");
@@ -2426,6 +2435,16 @@ __global__ __launch_bounds__((KT / 2) * (16 / RPT)) CETKMC_THERM16_ATTR void k_t
                 out[h] = v > C.clip_hi ? C.clip_hi : v;
             }
             *reinterpret_cast<double2*>(Tout + (int64_t)li * pstride + off[q]) = make_double2(out[0], out[1]);
+            if (TABLE) {
+                const double r0 = nuc_bulk(TB.T_melt, TB.delta_T_c, TB.kT, TB.I0, TB.rate_threshold, TB.K0, out[0]);
+                const double r1 = nuc_bulk(TB.T_melt, TB.delta_T_c, TB.kT, TB.I0, TB.rate_threshold, TB.K0, out[1]);
+                *reinterpret_cast<double2*>(TB.vval + (int64_t)li * pstride + off[q]) = make_double2(r0, r1);
+                if (i == L - 1) {                  // kmc_event_rates.py:59-63 for plane L-1 (block-uniform)
+                    double* dp = TB.dep_val + (int64_t)j * pitchT + k0;
+                    dp[0] = dep_rate_s(TB.nu_dep, TB.T_melt, TB.kT, pymax(out[0], 1.0));
+                    dp[1] = dep_rate_s(TB.nu_dep, TB.T_melt, TB.kT, pymax(out[1], 1.0));
+                }
+            }
         }
         __syncthreads();
 #pragma unroll

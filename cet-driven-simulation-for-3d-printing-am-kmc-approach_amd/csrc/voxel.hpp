@@ -131,9 +131,13 @@ __device__ __forceinline__ int nbj_rt(int m) { return (int)((0x1211225b2cbULL >>
 __device__ __forceinline__ int nbk_rt(int m) { return (int)((0x44922cb492ULL >> (3 * m)) & 7ULL) - 2; }
 
 // kmc_event_rates.py:60-63
+__device__ __forceinline__ double dep_rate_s(double nu_dep, double T_melt, double kT, double Tc)
+{
+    return nu_dep * exp(-(T_melt - Tc) / (kT * Tc));
+}
 __device__ __forceinline__ double dep_rate(const KParams& P, double Tc)
 {
-    return P.nu_dep * exp(-(P.T_melt - Tc) / (P.kT * Tc));
+    return dep_rate_s(P.nu_dep, P.T_melt, P.kT, Tc);
 }
 // exp(x) for x <= 0 (NaN -> 0): round-to-nearest reduction x = n*ln2 + r, |r| <= ln2/2, degree-13
 // Taylor polynomial in Horner form (truncation 4e-18), scaled by 2^n.  About 1 ulp; no overflow path

@@ -219,7 +219,9 @@ int cetkmc_sync(void* handle);
  * never set use it for L <= 128 and variant 1 above); "interface_every_step" 1 = evaluate the
  * whole interface list before every full sweep instead of only after a temperature update; "thermal_lookahead" 1 = the next
  * temperature update of a batch and its rate table are computed ahead on a second stream (single process; same bits;
- * default 0: measured slower); "thermal_variant" 0 = one thread per voxel, 1 = plane marching (default:
+ * default 0: measured slower); "thermal_table" 1 (default) = the default temperature tiles also write
+ * the new field's rate table and deposition rates (no k_rate_table launch after an update; same bits), 0 = separate launch;
+ * "thermal_variant" 0 = one thread per voxel, 1 = plane marching (default:
  * k_thermal_tiles16 -- 16 x 256 tiles, 1024 threads with 2 rows each, 16 planes per block -- where the tiles cover the lattice
  * exactly, else k_thermal_march), 2 = k_thermal_march everywhere, 3 = 16-row tiles with 4 rows per thread, 4 = the 8-row
  * k_thermal_tiles (round-2 kernel), 5 = 16 x 128 tiles (A/B variants);

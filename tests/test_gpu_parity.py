@@ -791,6 +791,40 @@ def test_thermal_lookahead_option_identical(n_slabs, thermal_mode):
     assert outs[0] == outs[1]
 
 
+@pytest.mark.parametrize("L,n_slabs,thermal_mode", [(256, 1, 2), (256, 2, 1), (512, 1, 2)])
+def test_thermal_table_fusion_identical(L, n_slabs, thermal_mode):
+    """thermal_table=1 (default): the 16 x 256 temperature tiles also write the new field's rate table and plane L-1's
+    deposition rates -- k_rate_table's work without a second pass over T.  Same functions on the same values: every total,
+    event, field and the stand-alone sweep are bit-identical to the separate launch (thermal_table=0), through temperature
+    updates with the laser source and latent heat, the cet update, several slabs, and the direct thermal calls."""
+    import cetkmc
+    from cetkmc import synthetic
+    n = 45 if L == 256 else 24
+    st, th, ph, T, df = synthetic.planes(L, 0, L, seed=5)
+    rs = np.random.RandomState(6)
+    u_pick, u_def, u_np = rs.random_sample(n), rs.random_sample(n), rs.random_sample(2 * n + 2)
+    q = synthetic.laser_planes(L, 0, n) if thermal_mode == 2 else None
+    outs = []
+    for fuse in (0, 1):
+        e = cetkmc.Engine(L, impurity_c=0.2, n_slabs=n_slabs)
+        e.set_option("thermal_table", fuse)
+        e.upload_planes(0, L, st, th, ph, T, df)
+        e.set_prev_state(None)
+        r = e.run_steps(0, n, 0.05, u_pick, u_def, u_np, rng_mode=1, seed=11, thermal_mode=thermal_mode, q_planes=q)
+        assert r["done"] == n and r["status"] == 0
+        e.thermal_cet(1e-6, True)                       # the direct calls of the drop-in thermal_solver
+        sw1 = e.rate_sweep()
+        e.thermal_laser(1e-6, synthetic.laser_planes(L, 0, 1)[0], use_latent=True)
+        sw2 = e.rate_sweep()
+        c = e.counters()
+        assert c["table_updates"] > 0
+        d = e.download_planes(0, L, state=True, theta=True, T=True)
+        outs.append((r["totals"].tobytes(), r["events"].tobytes(), r["n_events"].tobytes(), sw1, sw2,
+                     d["state"].tobytes(), d["theta"].tobytes(), d["T"].tobytes()))
+        e.close()
+    assert outs[0] == outs[1]
+
+
 def test_staged_inputs_identical_and_checked():
     """cetkmc_stage_inputs: a batch whose streams / source planes were copied ahead gives the same bits as the plain call;
     the library refuses a staged call whose shape differs from the staged batch, and a staged batch is used once."""
