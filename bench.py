@@ -680,11 +680,11 @@ def main():
                                      "HBM (working set exceeds the Infinity Cache)",
                      "hbm_512": hbm_512,
                      # the whole step against the same peak: algorithmic bytes of everything a step issues (sweep 9 B/voxel every
-                     # step; temperature update 16 B/voxel and rate-table refresh 16 B/voxel every 20 steps) over the device time
+                     # step; temperature update + rate table in one launch: T read, T and table entry written = 24 B/voxel every 20 steps) over the device time
                      # of a step -- the loop is latency-bound between its three launches (selection + application on one block)
-                     "step_level": {"alg_bytes_per_step": (B_ALG_SWEEP + 32.0 / 20.0) * n_own,
-                                    "achieved": (B_ALG_SWEEP + 32.0 / 20.0) * n_own / (r["wall_ms"] / a.steps * 1e-3) / 1e9,
-                                    "frac": (B_ALG_SWEEP + 32.0 / 20.0) * n_own / (r["wall_ms"] / a.steps * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "step_level": {"alg_bytes_per_step": (B_ALG_SWEEP + 24.0 / 20.0) * n_own,
+                                    "achieved": (B_ALG_SWEEP + 24.0 / 20.0) * n_own / (r["wall_ms"] / a.steps * 1e-3) / 1e9,
+                                    "frac": (B_ALG_SWEEP + 24.0 / 20.0) * n_own / (r["wall_ms"] / a.steps * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                     "unit": "GB/s"},
                      "traffic_measured_in_run": traffic_live,
                      "traffic_over_algorithmic": (traffic / (B_ALG_SWEEP * n_own)) if traffic else None,
