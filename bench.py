@@ -211,6 +211,9 @@ def main():
     dist = None
     uid = None
     if N > 1 or a.force_dist:
+        # this pool's host driver supports dmabuf IPC only: RCCL's buffer sharing across processes needs it (the environment
+        # normally exports it already)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch
         import torch.distributed as dist
         if "RANK" not in os.environ:             # plain `python bench.py --force-dist`
