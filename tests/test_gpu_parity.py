@@ -825,6 +825,137 @@ def test_thermal_table_fusion_identical(L, n_slabs, thermal_mode):
     assert outs[0] == outs[1]
 
 
+def _fuzz_case(seed):
+    """A random small problem: size, fill, species mix, model parameters and a temperature field with cold / hot / non-finite
+    voxels -- what no fixture of the reference holds in one place."""
+    rs = np.random.RandomState(1000 + seed)
+    L = int(rs.choice([5, 6, 7, 9, 11, 13, 16, 20]))
+    fill = float(rs.choice([0.0, 0.02, 0.2, 0.5, 0.9, 1.0]))
+    state = np.zeros((L, L, L), np.int64)
+    occ = rs.random_sample((L, L, L)) < fill
+    species = rs.choice([1, 2, 3, 4], size=(L, L, L), p=[0.5, 0.2, 0.2, 0.1])
+    state[occ] = species[occ]
+    every = bool(rs.randint(2))                           # orientations on empty sites too (the reference reads them)
+    theta = np.where(every | ((state != 0) & (state != 4)), rs.uniform(0, np.pi, (L, L, L)), 0.0)
+    phi = np.where(every | ((state != 0) & (state != 4)), rs.uniform(0, 2 * np.pi, (L, L, L)), 0.0)
+    kind = rs.randint(4)
+    if kind == 0:
+        T = rs.uniform(2600.0, 4064.5, (L, L, L))
+    elif kind == 1:
+        T = rs.uniform(0.2, 6000.0, (L, L, L))            # below 1 K (clamped by max(T, 1)) up to far above the melting point
+    elif kind == 2:
+        T = np.full((L, L, L), float(rs.choice([2800.0, 3000.0, 3684.9, 3695.0, 3700.0])))
+    else:
+        T = 2800.0 + (3695.0 - 2800.0) / L * np.arange(L)[None, None, :] + rs.uniform(-5, 5, (L, L, L))
+    weird = rs.random_sample((L, L, L)) < float(rs.choice([0.0, 0.0, 0.01]))
+    T = np.where(weird, rs.choice([np.nan, np.inf, -np.inf, 0.0, -40.0, 1e308], size=(L, L, L)), T)
+    defects = ((state != 0) & (rs.random_sample((L, L, L)) < 0.2)).astype(np.int64)
+    tweak = dict(nu_dep=float(rs.choice([1e6, 1e10, 1e13])), I0=float(rs.choice([0.0, 5e13, 1e20])),
+                 delta_T_c=float(rs.choice([0.0, 10.0, 400.0])), anisotropy=float(rs.choice([0.0, 0.25, 3.0])),
+                 rate_threshold=float(rs.choice([1e-30, 1e-3, 1e9])), K_nuc=float(rs.choice([50.0, 500.0, 5000.0])))
+    c = float(rs.choice([0.0, 0.1, 0.45]))
+    return L, (state, theta, phi, T, defects), tweak, c, rs
+
+
+@pytest.mark.parametrize("seed", range(36))
+def test_fuzz_random_problems_vs_oracle(oracle_mod, seed):
+    """Seeded random problems (see _fuzz_case): event list, row sums / counts / total, tree picks and 30 steps of the exact
+    loop with the reference's stream bookkeeping and temperature updates -- device against oracle, same bar as the fixtures
+    (types, positions, targets, counts and chosen events equal; rates / sums within 1e-11)."""
+    import cetkmc
+    L, fields, tweak, c, rs = _fuzz_case(seed)
+    params = cetkmc.default_params(c)
+    for k, v in tweak.items():
+        setattr(params, k, v)
+    e = cetkmc.Engine(L, impurity_c=c, params=params)
+    e.upload(*fields)
+    lat = oracle_mod.Lattice(*fields, impurity_c=c)
+    for k, v in tweak.items():
+        setattr(lat.params, k, v)
+    ev_o, nd_o = lat.enumerate()
+    ev_g, n_g = e.enumerate_events()
+    assert n_g == len(ev_o)
+    for f in ("type", "pos", "target"):
+        assert np.array_equal(ev_g[f], ev_o[f]), f
+    if n_g:
+        fin = np.isfinite(ev_o["rate"])
+        assert np.array_equal(np.isfinite(ev_g["rate"]), fin)
+        assert relerr(ev_g["rate"][fin], ev_o["rate"][fin]).max() <= RATE_RTOL
+    sw = lat.sweep()
+    total, n_events, n_dep = e.rate_sweep()
+    rsum, rcnt = e.row_sums()
+    assert (n_events, n_dep) == (sw["n_events"], sw["n_dep"]) and np.array_equal(rcnt, sw["rowcnt"])
+    fin = np.isfinite(sw["rowsum"])
+    assert np.array_equal(np.isfinite(rsum), fin)
+    assert relerr(rsum[fin], sw["rowsum"][fin]).max() <= RATE_RTOL if fin.any() else True
+    if n_events and np.isfinite(sw["total"]) and sw["total"] >= 1e-25:
+        for u in rs.random_sample(12):
+            want = lat.select_tree(sw["blocksum"], sw["blockcnt"], sw["rowsum"], sw["rowcnt"], u * sw["total"])
+            got = e.select(u * total)
+            assert (got.type, tuple(got.pos), tuple(got.target), got.dep_rank) == \
+                   (want.type, tuple(want.pos), tuple(want.target), want.dep_rank), u
+    n = 30
+    u_pick, u_def, u_np = rs.random_sample(n), rs.random_sample(n), rs.random_sample(n * (L * L + 2))
+    rg = e.run_steps(0, n, 0.1, u_pick, u_def, u_np, rng_mode=0, thermal_mode=1)
+    ro = lat.run_steps(0, n, 0.1, u_pick, u_def, u_np, rng_mode=0, thermal_mode=1)
+    assert (rg["done"], rg["status"], rg["np_used"]) == (ro["done"], ro["status"], ro["np_used"])
+    for f in ("type", "pos", "target", "atom"):
+        assert np.array_equal(rg["events"][f], ro["events"][f]), f
+    assert np.array_equal(rg["n_events"], ro["n_events"])
+    if rg["done"]:
+        assert relerr(rg["totals"][:rg["done"]], ro["totals"][:rg["done"]]).max() <= RATE_RTOL
+    d = e.download()
+    assert np.array_equal(d["state"], lat.state) and np.array_equal(d["theta"], lat.theta) and np.array_equal(d["phi"], lat.phi)
+    assert np.array_equal(d["T"], lat.T, equal_nan=True)
+    e.close()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_modes_vs_oracle(oracle_mod, seed):
+    """The same random problems through the other ways of stepping: several slabs, the exact incremental loop with the counter
+    species draw, and Mode B super-steps (box 8, with and without null events) -- all against the oracle's full evaluation."""
+    import cetkmc
+    L0, fields, tweak, c, rs = _fuzz_case(100 + seed)
+    L = 16 if L0 <= 11 else 24                           # a multiple of the box
+    rs2 = np.random.RandomState(77 + seed)
+    reps = -(-L // L0)
+    fields = tuple(np.tile(f, (reps, reps, reps))[:L, :L, :L].copy() for f in fields)
+    params = cetkmc.default_params(c)
+    for k, v in tweak.items():
+        setattr(params, k, v)
+    n_slabs = int(rs2.choice([1, 2, 3]))
+    e = cetkmc.Engine(L, impurity_c=c, params=params, n_slabs=n_slabs)
+    e.upload(*fields)
+    lat = oracle_mod.Lattice(*fields, impurity_c=c)
+    for k, v in tweak.items():
+        setattr(lat.params, k, v)
+    n = 45
+    u_pick, u_def, u_np = rs2.random_sample(n), rs2.random_sample(n), rs2.random_sample(2 * n + 2)
+    rg = e.run_steps(3, n, 0.05, u_pick, u_def, u_np, rng_mode=1, seed=seed, thermal_mode=1, incremental=True)
+    ro = lat.run_steps(3, n, 0.05, u_pick, u_def, u_np, rng_mode=1, seed=seed, thermal_mode=1)
+    assert (rg["done"], rg["status"], rg["np_used"]) == (ro["done"], ro["status"], ro["np_used"])
+    for f in ("type", "pos", "target", "atom"):
+        assert np.array_equal(rg["events"][f], ro["events"][f]), f
+    assert np.array_equal(rg["n_events"], ro["n_events"])
+    if rg["status"] == 0:
+        for null in (False, True):
+            g0 = 3 + n + (20 if null else 0)
+            bg = e.run_supersteps(g0, 12, 8, 0.05, seed=seed, thermal_mode=1, want_events=True, null_events=null)
+            bo = lat.run_supersteps(g0, 12, 8, 0.05, seed, thermal_mode=1, null_events=null)
+            assert (bg["done"], bg["status"]) == (bo["done"], bo["status"])
+            for f in ("type", "pos", "target", "atom"):
+                assert np.array_equal(bg["events"][f], bo["events"][f]), (null, f)
+            assert np.array_equal(bg["n_exec"], bo["n_exec"])
+            if bg["done"]:
+                assert relerr(bg["totals"][:bg["done"]], bo["totals"][:bg["done"]]).max() <= RATE_RTOL
+            if bg["status"]:
+                break
+    d = e.download()
+    assert np.array_equal(d["state"], lat.state) and np.array_equal(d["theta"], lat.theta) and np.array_equal(d["phi"], lat.phi)
+    assert np.array_equal(d["T"], lat.T, equal_nan=True)
+    e.close()
+
+
 def test_staged_inputs_identical_and_checked():
     """cetkmc_stage_inputs: a batch whose streams / source planes were copied ahead gives the same bits as the plain call;
     the library refuses a staged call whose shape differs from the staged batch, and a staged batch is used once."""
