@@ -158,6 +158,34 @@ def gen_events():
              seq_total=seq_total, **pack_events(ev))
 
 
+def gen_events_odd():
+    """Event lists on inputs the crafted cases above do not hold: non-finite temperatures (NaN, +-inf, 1e308) scattered over
+    the lattice and on plane L-1, a completely filled and a completely empty lattice, orientations on empty sites."""
+    cases = [
+        # name, L, seed, fill, nonzero-empty-orientation, impurity_c, fraction of non-finite temperatures
+        ("events_L7_nonfinite", 7, 31, 0.30, False, 0.1, 0.08),
+        ("events_L8_nonfinite_orient", 8, 32, 0.45, True, 0.2, 0.05),
+        ("events_L5_full", 5, 33, 1.0, False, 0.1, 0.0),
+        ("events_L6_empty_nonfinite", 6, 34, 0.0, False, 0.3, 0.10),
+        ("events_L4_dense_nonfinite", 4, 35, 0.8, True, 0.0, 0.15),
+    ]
+    for name, L, seed, fill, nze, c, frac in cases:
+        state, theta, phi, T, defects = crafted_lattice(L, seed, fill, nze, "mixed")
+        rs = np.random.RandomState(500 + seed)
+        odd = rs.random_sample((L, L, L)) < frac
+        T = np.where(odd, rs.choice([np.nan, np.inf, -np.inf, 1e308, -1e308], size=(L, L, L)), T)
+        np.random.seed(1000 + seed)
+        with np.errstate(all="ignore"):
+            ev = ref_rates.get_event_rates(state, theta, phi, T, state.copy(), defects, L, 1, 2, 3,
+                                           step=0, debug_step=1000, impurity_c=c)
+        seq_total = 0.0
+        for e in ev:
+            seq_total += e[2]
+        save(name, L=L, state=state.astype(np.int8), theta=theta, phi=phi, T=T,
+             defects=defects.astype(np.int8), impurity_c=c, np_seed=1000 + seed,
+             seq_total=seq_total, **pack_events(ev))
+
+
 # --------------------------------------------------------------------------
 # helper lattice used by several generators: the bench "config 2/3" fill rule
 # --------------------------------------------------------------------------
@@ -430,7 +458,7 @@ def gen_metrics():
     print("  wrote metrics_meta.json")
 
 
-GENS = dict(events=gen_events, events_init=gen_events_initlattice, traj=gen_traj, thermal=gen_thermal,
+GENS = dict(events=gen_events, events_odd=gen_events_odd, events_init=gen_events_initlattice, traj=gen_traj, thermal=gen_thermal,
             init_defects=gen_init_defects, metrics=gen_metrics)
 
 if __name__ == "__main__":
