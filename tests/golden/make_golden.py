@@ -263,9 +263,16 @@ def gen_traj():
         ("traj_L7_n230_T3400", dict(L=7, n_steps=230, temp=3400, defect_fraction=0.02, n_seeds=4, impurity_c=0.3)),
         ("traj_L30_n3", dict(L=30, n_steps=3, temp=2800, defect_fraction=3e-3, n_seeds=20, impurity_c=0.2)),
         ("traj_L32_n1", dict(L=32, n_steps=1, temp=2800, defect_fraction=0.0, n_seeds=5, impurity_c=0.0)),
+        # substrate temperature within delta_T_c of the melting point: no nucleation anywhere; the small lattice fills up and
+        # the run ends through the reference's "no valid events" branch (kmc_simulation.py:259-262) before n_steps
+        ("traj_L3_n80_T3690_terminates", dict(L=3, n_steps=80, temp=3690, defect_fraction=0.0, n_seeds=2, impurity_c=0.1)),
+        ("traj_L4_n200_T3688_terminates", dict(L=4, n_steps=200, temp=3688, defect_fraction=0.05, n_seeds=3, impurity_c=0.3)),
     ]
+    only = os.environ.get("TRAJ_ONLY")            # regenerate one case: TRAJ_ONLY=traj_L3 python make_golden.py --only traj
     orig = ref_sim.get_event_rates
     for name, kw in cases:
+        if only and not name.startswith(only):
+            continue
         rec = Recorder(orig)
         ref_sim.get_event_rates = rec
         buf = io.StringIO()
