@@ -589,7 +589,7 @@ def main():
             if N == 1 and L == 256 and "hbm_bytes_per_launch" in kk:
                 traffic, traffic_src, rocprof_ms = kk["hbm_bytes_per_launch"], os.path.relpath(summary_path, ROOT), kk["avg_us"] * 1e-3
                 rocprof_kernels = {k: round(allk[k]["avg_us"], 2) for k in ("k_sweep_stream", "k_plane_reduce", "k_select_apply",
-                                                                            "k_thermal_tiles", "k_thermal_march", "k_rate_table",
+                                                                            "k_thermal_tiles16", "k_thermal_tiles", "k_thermal_march", "k_rate_table",
                                                                             "k_interface", "k_clear_row_flags") if k in allk and "avg_us" in allk[k]}
                 break
         except Exception:
@@ -599,7 +599,7 @@ def main():
     if traffic_live:
         traffic, traffic_src = live_bytes, live_src
     if phases is not None and rocprof_kernels:
-        per_update = sum(rocprof_kernels.get(k, 0.0) for k in ("k_thermal_tiles", "k_thermal_march", "k_rate_table", "k_interface", "k_clear_row_flags"))
+        per_update = sum(rocprof_kernels.get(k, 0.0) for k in ("k_thermal_tiles16", "k_thermal_tiles", "k_thermal_march", "k_rate_table", "k_interface", "k_clear_row_flags"))
         phases["rocprof"] = {
             "kernel_avg_us": rocprof_kernels, "source": summary_src,
             "select_apply_plus_reduce_plus_interface_us_per_step":
