@@ -263,6 +263,10 @@ def gen_traj():
         ("traj_L7_n230_T3400", dict(L=7, n_steps=230, temp=3400, defect_fraction=0.02, n_seeds=4, impurity_c=0.3)),
         ("traj_L30_n3", dict(L=30, n_steps=3, temp=2800, defect_fraction=3e-3, n_seeds=20, impurity_c=0.2)),
         ("traj_L32_n1", dict(L=32, n_steps=1, temp=2800, defect_fraction=0.0, n_seeds=5, impurity_c=0.0)),
+        # the 9^3 lattice is full after 760 events: the run ends through the termination branch at the default temperature
+        ("traj_L9_n2500", dict(L=9, n_steps=2500, temp=2800, defect_fraction=0.004, n_seeds=4, impurity_c=0.15)),
+        # a long one: 2500 steps -- twelve defect refreshes, 14 metrics rows, 82 % of the lattice filled at the end
+        ("traj_L14_n2500", dict(L=14, n_steps=2500, temp=2800, defect_fraction=0.004, n_seeds=5, impurity_c=0.15)),
         # substrate temperature within delta_T_c of the melting point: no nucleation anywhere; the small lattice fills up and
         # the run ends through the reference's "no valid events" branch (kmc_simulation.py:259-262) before n_steps
         ("traj_L3_n80_T3690_terminates", dict(L=3, n_steps=80, temp=3690, defect_fraction=0.0, n_seeds=2, impurity_c=0.1)),
